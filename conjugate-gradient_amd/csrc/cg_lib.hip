@@ -1,0 +1,879 @@
+// Host side of libcg_hip.so: the C ABI declared in include/cg_hip.h.
+//
+// One cg_ctx owns one row block of the four CG vectors in the HBM of one GPU,
+// a private HIP stream, the device-resident scalar state and (optionally) a
+// captured hipGraph of the iteration body.  The host never reads a scalar inside
+// the iteration loop; tau, beta and the stop flag are produced and consumed on
+// the device (cg_kernels.hpp, k_finish).
+#include "cg_kernels.hpp"
+#include "../../include/cg_hip.h"
+#include "cg_comm.hpp"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(CG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define CGCHK(expr)                       \
+    do {                                  \
+        int rc_ = (expr);                 \
+        if (rc_ != CG_OK) return rc_;     \
+    } while (0)
+
+using cg::kBlock;
+using cg::Scalars;
+using cg::StencilArgs;
+
+constexpr int kMaxFlatBlocks = 2048;      // 256 CUs x 8 resident workgroups
+constexpr int kMaxDevices = 64;
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int select_device(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(CG_ERR_NOGPU, "no HIP device visible: the CG hot path has no CPU fallback");
+    if (device < 0 || device >= count)
+        return fail(CG_ERR_ARG, "device %d out of range (%d visible)", device, count);
+    HIPCHK(hipSetDevice(device));
+    return CG_OK;
+}
+
+// Per-device resources of the stand-alone operator entry points.
+struct DeviceScratch {
+    hipStream_t stream = nullptr;
+    double *partials = nullptr;            // kMaxPartials doubles
+    Scalars *sc = nullptr;
+    double *slot = nullptr;                // strict-dot result
+    bool ready = false;
+};
+constexpr long kMaxPartials = 1 << 16;
+DeviceScratch g_scratch[kMaxDevices];
+std::mutex g_scratch_mu;
+
+int get_scratch(int device, DeviceScratch **out)
+{
+    CGCHK(select_device(device));
+    if (device >= kMaxDevices) return fail(CG_ERR_ARG, "device index too large");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    DeviceScratch &s = g_scratch[device];
+    if (!s.ready) {
+        HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIPCHK(hipMalloc(&s.partials, kMaxPartials * sizeof(double)));
+        HIPCHK(hipMalloc(&s.sc, sizeof(Scalars)));
+        HIPCHK(hipMalloc(&s.slot, sizeof(double)));
+        HIPCHK(hipMemset(s.sc, 0, sizeof(Scalars)));
+        s.ready = true;
+    }
+    *out = &s;
+    return CG_OK;
+}
+
+int flat_blocks(long nvec, long want)
+{
+    long b = (nvec + kBlock - 1) / kBlock;
+    const long cap = want > 0 ? want : kMaxFlatBlocks;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// Geometry of the tiled (stencil-shaped) kernels for one row block.
+struct TileGeom {
+    int vec;          // 2 when rows are 16-byte aligned (even G), else 1
+    int nstrips;
+    int tile_h;
+    long ntiles;
+};
+
+TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
+{
+    TileGeom t;
+    t.vec = (G % 2 == 0 && all_aligned) ? 2 : 1;
+    const long W = (long)kBlock * t.vec;
+    t.nstrips = (int)((G + W - 1) / W);
+    long h = tile_h_opt;
+    if (h <= 0) {
+        // Aim for a few thousand tiles (>= 8 per CU) but keep the two halo rows a
+        // tile re-reads below ~6 % of its traffic.
+        h = rows * t.nstrips / 4096;
+        if (h < 32) h = 32;
+        if (h > 128) h = 128;
+    }
+    if (h > rows) h = rows;
+    if (h < 1) h = 1;
+    t.tile_h = (int)h;
+    t.ntiles = (long)t.nstrips * ((rows + h - 1) / h);
+    return t;
+}
+
+template <int MODE, bool WRITE_Q>
+void launch_stencil(const TileGeom &t, const StencilArgs &a, hipStream_t s)
+{
+    if (t.vec == 2)
+        hipLaunchKernelGGL((cg::k_stencil<2, MODE, WRITE_Q>), dim3((unsigned)t.ntiles), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((cg::k_stencil<1, MODE, WRITE_Q>), dim3((unsigned)t.ntiles), dim3(kBlock), 0, s, a);
+}
+
+} // namespace
+
+// =========================================================================
+// Context
+// =========================================================================
+
+struct cg_ctx {
+    int device = 0;
+    long n = 0, G = 0, row0 = 0, rows = 0, count = 0;
+    int rank = 0, nranks = 1;
+
+    // options
+    int reduce = CG_REDUCE_FAST;
+    int schedule = -1;                    // -1 = pick from `reduce`
+    long tile_h = 0;
+    long graph_iters = 10;
+    int remap = 1;
+    long flat_blocks_opt = 0;
+
+    // device state
+    hipStream_t stream = nullptr;
+    double *u = nullptr, *g = nullptr, *q = nullptr;
+    double *d[2] = {nullptr, nullptr};
+    int dcur = 0;                         // which of d[] holds the current direction
+    bool pending_dupdate = false;         // fused schedules: last d update not yet applied
+    double *partials = nullptr;           // 2 * npart doubles (d.q | g.g)
+    long npart = 0;
+    Scalars *sc = nullptr;
+    double *strict_slot = nullptr;
+    double *hist = nullptr;
+    long hist_cap = 0;
+    long hist_len = 0;
+    bool q_valid = true;
+
+    // halo rows (multi-GPU).  *_top = the row above the block, *_bot = below.
+    double *halo_d[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [buffer][top/bot]
+    double *halo_g[2] = {nullptr, nullptr};
+    cg::Comm *comm = nullptr;
+
+    // captured iteration body
+    hipGraphExec_t graph = nullptr;
+    long graph_len = 0;                   // iterations in the captured graph
+    int graph_sched = -1, graph_reduce = -1, graph_dcur = -1;
+    Scalars *host_sc = nullptr;           // pinned read-back buffer
+
+    int effective_schedule() const
+    {
+        if (schedule >= 0) return schedule;
+        return reduce == CG_REDUCE_STRICT ? CG_SCHED_CLASSIC : CG_SCHED_FUSED_NOQ;
+    }
+    bool has_top() const { return row0 > 0; }
+    bool has_bot() const { return row0 + rows < G; }
+};
+
+namespace {
+
+TileGeom ctx_geom(const cg_ctx *c) { return tile_geom(c->G, c->rows, true, c->tile_h); }
+
+int comm_rc(const cg_ctx *c, int rc)
+{
+    return rc == 0 ? CG_OK : fail(CG_ERR_COMM, "rank %d: %s", c->rank, c->comm->error());
+}
+
+void drop_graph(cg_ctx *c)
+{
+    if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    c->graph_len = 0;
+}
+
+// ---- one CG iteration, enqueued on the context's stream -------------------
+//
+// `first` = this is iteration 0 of a freshly initialised problem, for which
+// the fused schedules have no pending d update.  Every launch is
+// stream-ordered; nothing here synchronises, so the same code runs eagerly and
+// under stream capture.
+int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *partials, long npart,
+                       int what, double rtol)
+{
+    // Completes a dot product whose fast-order block partials are already in
+    // `partials` (npart of them), or, in strict mode, recomputes it with the
+    // sequential kernel from v and w; then runs the scalar recurrence `what`.
+    hipStream_t s = c->stream;
+    const double *src = nullptr;
+    if (c->reduce == CG_REDUCE_STRICT) {
+        if (c->nranks > 1) return fail(CG_ERR_STATE, "strict reduction order is single-GPU only");
+        hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, c->strict_slot);
+        src = c->strict_slot;
+    } else if (c->nranks > 1) {
+        // local fixed-order sum -> all ranks' sums (RCCL all-gather) -> rank-order sum
+        double *mine = c->comm->gather_buf() + c->rank;
+        hipLaunchKernelGGL(cg::k_partial_sum, dim3(1), dim3(kBlock), 0, s, partials, npart, what < 2 ? c->sc : nullptr, mine);
+        CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+        hipLaunchKernelGGL(cg::k_rank_sum, dim3(1), dim3(64), 0, s, c->comm->gather_buf(), c->nranks, c->strict_slot);
+        src = c->strict_slot;
+    }
+    hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, partials, npart, src, c->sc, what, rtol,
+                       c->hist, c->hist_cap);
+    return CG_OK;
+}
+
+StencilArgs base_args(cg_ctx *c, const TileGeom &t)
+{
+    StencilArgs a;
+    memset(&a, 0, sizeof a);
+    a.sc = c->sc;
+    a.G = c->G; a.rows = c->rows; a.row0 = c->row0;
+    a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = c->remap;
+    return a;
+}
+
+int enqueue_iteration(cg_ctx *c, bool first)
+{
+    hipStream_t s = c->stream;
+    const int sched = c->effective_schedule();
+    const TileGeom t = ctx_geom(c);
+    double *p_dq = c->partials, *p_gg = c->partials + c->npart;
+    const long nvec = c->count / t.vec;
+    const int fb = flat_blocks(nvec, c->flat_blocks_opt);
+
+    // ---- q = A d (+ d.q), with the pending d update folded in where scheduled
+    StencilArgs a = base_args(c, t);
+    a.partials = p_dq;
+    a.q = c->q;
+    const bool fuse = (sched != CG_SCHED_CLASSIC) && !first;
+    if (c->nranks > 1) {
+        // Row halos: the fused kernel needs the neighbours' boundary rows of g (d's
+        // halo rows are kept current locally); the plain kernel needs those of d.
+        if (fuse) CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
+        else if (!first || sched == CG_SCHED_CLASSIC)
+            CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->d[c->dcur], c->rows, c->G, c->halo_d[c->dcur][0], c->halo_d[c->dcur][1])));
+    }
+    if (fuse) {
+        const int in = c->dcur, out = c->dcur ^ 1;
+        a.d_in = c->d[in]; a.g = c->g; a.d_out = c->d[out];
+        a.d_top = c->has_top() ? c->halo_d[in][0] : nullptr;
+        a.d_bot = c->has_bot() ? c->halo_d[in][1] : nullptr;
+        a.g_top = c->has_top() ? c->halo_g[0] : nullptr;
+        a.g_bot = c->has_bot() ? c->halo_g[1] : nullptr;
+        a.d_top_out = c->has_top() ? c->halo_d[out][0] : nullptr;
+        a.d_bot_out = c->has_bot() ? c->halo_d[out][1] : nullptr;
+        if (sched == CG_SCHED_FUSED) launch_stencil<1, true>(t, a, s);
+        else launch_stencil<1, false>(t, a, s);
+        c->dcur = out;
+    } else {
+        a.d_in = c->d[c->dcur];
+        a.d_top = c->has_top() ? c->halo_d[c->dcur][0] : nullptr;
+        a.d_bot = c->has_bot() ? c->halo_d[c->dcur][1] : nullptr;
+        if (sched == CG_SCHED_FUSED_NOQ) launch_stencil<0, false>(t, a, s);
+        else launch_stencil<0, true>(t, a, s);
+    }
+    HIPCHK(hipGetLastError());
+    CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0));
+
+    // ---- u += tau d ; g += tau q (+ g.g)
+    long npart_gg;
+    if (sched == CG_SCHED_FUSED_NOQ) {
+        StencilArgs b = base_args(c, t);
+        b.d_in = c->d[c->dcur];
+        b.d_top = c->has_top() ? c->halo_d[c->dcur][0] : nullptr;
+        b.d_bot = c->has_bot() ? c->halo_d[c->dcur][1] : nullptr;
+        b.u = c->u; b.gw = c->g; b.partials = p_gg;
+        launch_stencil<2, false>(t, b, s);
+        npart_gg = t.ntiles;
+    } else {
+        if (t.vec == 2)
+            hipLaunchKernelGGL(cg::k_update<2>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg);
+        else
+            hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg);
+        npart_gg = fb;
+    }
+    HIPCHK(hipGetLastError());
+    CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0));
+
+    // ---- d = beta d - g: now (classic) or inside the next stencil kernel (fused)
+    if (sched == CG_SCHED_CLASSIC) {
+        if (t.vec == 2)
+            hipLaunchKernelGGL(cg::k_dupdate<2>, dim3(fb), dim3(kBlock), 0, s, c->d[c->dcur], c->g, c->count, c->sc, 1);
+        else
+            hipLaunchKernelGGL(cg::k_dupdate<1>, dim3(fb), dim3(kBlock), 0, s, c->d[c->dcur], c->g, c->count, c->sc, 1);
+        HIPCHK(hipGetLastError());
+    }
+    return CG_OK;
+}
+
+// The d update a fused schedule still owes after its last iteration: applied
+// once, so that d ends in the state the reference leaves it in (cg.c:81-87 runs
+// before the loop exits).  beta is the one computed by the last k_finish.
+int flush_pending_dupdate(cg_ctx *c)
+{
+    if (!c->pending_dupdate) return CG_OK;
+    const TileGeom t = ctx_geom(c);
+    const long nvec = c->count / t.vec;
+    const int fb = flat_blocks(nvec, c->flat_blocks_opt);
+    if (t.vec == 2)
+        hipLaunchKernelGGL(cg::k_dupdate<2>, dim3(fb), dim3(kBlock), 0, c->stream, c->d[c->dcur], c->g, c->count, c->sc, 0);
+    else
+        hipLaunchKernelGGL(cg::k_dupdate<1>, dim3(fb), dim3(kBlock), 0, c->stream, c->d[c->dcur], c->g, c->count, c->sc, 0);
+    HIPCHK(hipGetLastError());
+    if (c->nranks > 1) {
+        // keep the locally maintained halo rows of d consistent with the flushed state
+        CGCHK(comm_rc(c, c->comm->exchange_rows(c->stream, c->d[c->dcur], c->rows, c->G, c->halo_d[c->dcur][0], c->halo_d[c->dcur][1])));
+    }
+    c->pending_dupdate = false;
+    return CG_OK;
+}
+
+// Capture `len` iterations (none of them the first) into a graph.  Fused
+// schedules swap d's buffers every iteration, so len is forced even and the
+// buffer roles are the same at every replay.
+int build_graph(cg_ctx *c, long len)
+{
+    drop_graph(c);
+    const int sched = c->effective_schedule();
+    if (sched != CG_SCHED_CLASSIC && (len & 1)) ++len;
+    hipGraph_t graph = nullptr;
+    const int dcur0 = c->dcur;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = CG_OK;
+    for (long i = 0; i < len && rc == CG_OK; ++i) rc = enqueue_iteration(c, false);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    c->dcur = dcur0;                       // capture executed nothing
+    if (rc != CG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(CG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { c->graph = nullptr; return fail(CG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    c->graph_len = len;
+    c->graph_sched = sched;
+    c->graph_reduce = c->reduce;
+    c->graph_dcur = dcur0;
+    return CG_OK;
+}
+
+} // namespace
+
+// =========================================================================
+// extern "C"
+// =========================================================================
+
+extern "C" {
+
+const char *cg_last_error(void) { return g_err; }
+
+int cg_device_count(int *count)
+{
+    if (!count) return fail(CG_ERR_ARG, "count is NULL");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return CG_OK;
+}
+
+int cg_malloc(int device, long count, double **out)
+{
+    if (!out || count <= 0) return fail(CG_ERR_ARG, "cg_malloc: bad arguments");
+    CGCHK(select_device(device));
+    HIPCHK(hipMalloc(out, (size_t)count * sizeof(double)));
+    HIPCHK(hipMemset(*out, 0, (size_t)count * sizeof(double)));
+    return CG_OK;
+}
+
+int cg_free(int device, double *p)
+{
+    CGCHK(select_device(device));
+    HIPCHK(hipFree(p));
+    return CG_OK;
+}
+
+int cg_copy_to_host(int device, double *host_dst, const double *dev_src, long count)
+{
+    if (!host_dst || !dev_src || count < 0) return fail(CG_ERR_ARG, "cg_copy_to_host: bad arguments");
+    CGCHK(select_device(device));
+    HIPCHK(hipMemcpy(host_dst, dev_src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return CG_OK;
+}
+
+int cg_copy_to_device(int device, double *dev_dst, const double *host_src, long count)
+{
+    if (!dev_dst || !host_src || count < 0) return fail(CG_ERR_ARG, "cg_copy_to_device: bad arguments");
+    CGCHK(select_device(device));
+    HIPCHK(hipMemcpy(dev_dst, host_src, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    return CG_OK;
+}
+
+int cg_init_d(int device, long n, long row0, long rows, double *d)
+{
+    if (!d || n < 2 || rows < 1 || row0 < 0 || row0 + rows > n + 1)
+        return fail(CG_ERR_ARG, "cg_init_d: need n >= 2 and 0 <= row0 < row0+rows <= n+1");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    const long G = n + 1;
+    const double h = (double)1 / (double)n;             // utils.c:323
+    hipLaunchKernelGGL(cg::k_init_d, dim3(flat_blocks(rows * G, 0)), dim3(kBlock), 0, sc->stream, d, G, row0, rows, h);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
+int cg_init_g(int device, long count, const double *d, double *g)
+{
+    if (!d || !g || count < 1) return fail(CG_ERR_ARG, "cg_init_g: bad arguments");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    hipLaunchKernelGGL(cg::k_init_g, dim3(flat_blocks(count, 0)), dim3(kBlock), 0, sc->stream, g, d, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
+int cg_stencil(int device, long G, long row0, long rows, const double *d, const double *top,
+               const double *bot, double *q, double *dq_host)
+{
+    if (!d || !q || G < 3 || rows < 1 || row0 < 0 || row0 + rows > G)
+        return fail(CG_ERR_ARG, "cg_stencil: need G >= 3 and 0 <= row0 < row0+rows <= G");
+    if ((row0 > 0 && !top) || (row0 + rows < G && !bot))
+        return fail(CG_ERR_ARG, "cg_stencil: a block that does not touch the global boundary needs its halo row");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    const bool al = aligned16(d) && aligned16(q) && (!top || aligned16(top)) && (!bot || aligned16(bot));
+    const TileGeom t = tile_geom(G, rows, al, 0);
+    if (t.ntiles > kMaxPartials) return fail(CG_ERR_ARG, "cg_stencil: block too large for the stand-alone entry point");
+    StencilArgs a;
+    memset(&a, 0, sizeof a);
+    a.d_in = d; a.d_top = row0 > 0 ? top : nullptr; a.d_bot = row0 + rows < G ? bot : nullptr;
+    a.q = q; a.partials = sc->partials; a.sc = nullptr;
+    a.G = G; a.rows = rows; a.row0 = row0; a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = 1;
+    launch_stencil<0, true>(t, a, sc->stream);
+    HIPCHK(hipGetLastError());
+    if (dq_host) {
+        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, sc->stream, sc->partials, t.ntiles,
+                           (const double *)nullptr, sc->sc, 3, 0.0, (double *)nullptr, 0L);
+        HIPCHK(hipGetLastError());
+        Scalars h;
+        HIPCHK(hipMemcpyAsync(&h, sc->sc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
+        HIPCHK(hipStreamSynchronize(sc->stream));
+        *dq_host = h.dot;
+    } else {
+        HIPCHK(hipStreamSynchronize(sc->stream));
+    }
+    return CG_OK;
+}
+
+int cg_dot(int device, long count, const double *v, const double *w, int strict, double start,
+           double *result_host)
+{
+    if (!v || !w || !result_host || count < 0) return fail(CG_ERR_ARG, "cg_dot: bad arguments");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    if (strict) {
+        hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, sc->stream, v, w, count, start, sc->slot);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(result_host, sc->slot, sizeof(double), hipMemcpyDeviceToHost, sc->stream));
+        HIPCHK(hipStreamSynchronize(sc->stream));
+        return CG_OK;
+    }
+    const int vec = (count % 2 == 0 && aligned16(v) && aligned16(w)) ? 2 : 1;
+    const int fb = flat_blocks(count / vec, 0);
+    if (vec == 2)
+        hipLaunchKernelGGL(cg::k_dot_partial<2>, dim3(fb), dim3(kBlock), 0, sc->stream, v, w, count, sc->partials);
+    else
+        hipLaunchKernelGGL(cg::k_dot_partial<1>, dim3(fb), dim3(kBlock), 0, sc->stream, v, w, count, sc->partials);
+    hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, sc->stream, sc->partials, (long)fb,
+                       (const double *)nullptr, sc->sc, 3, 0.0, (double *)nullptr, 0L);
+    HIPCHK(hipGetLastError());
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(&h, sc->sc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    *result_host = h.dot + start;
+    return CG_OK;
+}
+
+int cg_axpy(int device, long count, double a, const double *x, double *y)
+{
+    if (!x || !y || count < 0) return fail(CG_ERR_ARG, "cg_axpy: bad arguments");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    const int vec = (count % 2 == 0 && aligned16(x) && aligned16(y)) ? 2 : 1;
+    const int fb = flat_blocks(count / vec, 0);
+    if (vec == 2) hipLaunchKernelGGL(cg::k_axpy<2>, dim3(fb), dim3(kBlock), 0, sc->stream, y, x, a, count);
+    else hipLaunchKernelGGL(cg::k_axpy<1>, dim3(fb), dim3(kBlock), 0, sc->stream, y, x, a, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
+int cg_xpay(int device, long count, double b, double *d, const double *g)
+{
+    if (!d || !g || count < 0) return fail(CG_ERR_ARG, "cg_xpay: bad arguments");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    const int vec = (count % 2 == 0 && aligned16(d) && aligned16(g)) ? 2 : 1;
+    const int fb = flat_blocks(count / vec, 0);
+    if (vec == 2) hipLaunchKernelGGL(cg::k_xpay<2>, dim3(fb), dim3(kBlock), 0, sc->stream, d, g, b, count);
+    else hipLaunchKernelGGL(cg::k_xpay<1>, dim3(fb), dim3(kBlock), 0, sc->stream, d, g, b, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
+// ---------------------------------------------------------------- context ---
+
+int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks)
+{
+    if (!out) return fail(CG_ERR_ARG, "cg_create: out is NULL");
+    *out = nullptr;
+    if (n < 2) return fail(CG_ERR_ARG, "cg_create: n must be >= 2 (got %ld)", n);
+    const long G = n + 1;
+    if (rows < 1 || row0 < 0 || row0 + rows > G)
+        return fail(CG_ERR_ARG, "cg_create: rows [%ld,%ld) outside the %ld-row grid", row0, row0 + rows, G);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(CG_ERR_ARG, "cg_create: bad rank %d of %d", rank, nranks);
+    if (nranks == 1 && (row0 != 0 || rows != G))
+        return fail(CG_ERR_ARG, "cg_create: a single rank must own the whole grid");
+    CGCHK(select_device(device));
+
+    cg_ctx *c = new cg_ctx;
+    c->device = device; c->n = n; c->G = G; c->row0 = row0; c->rows = rows; c->count = rows * G;
+    c->rank = rank; c->nranks = nranks;
+    const size_t bytes = (size_t)c->count * sizeof(double);
+    // The most tiles any tile_h option can produce: one row per tile.
+    c->npart = (long)((G + kBlock - 1) / kBlock) * rows;
+    if (c->npart < kMaxFlatBlocks) c->npart = kMaxFlatBlocks;
+    if (c->npart > (1L << 22)) c->npart = 1L << 22;
+    int rc = CG_OK;
+    auto alloc = [&](double **p, size_t b) {
+        if (rc != CG_OK) return;
+        hipError_t e = hipMalloc(p, b);
+        if (e != hipSuccess) rc = fail(CG_ERR_HIP, "hipMalloc(%zu bytes): %s", b, hipGetErrorString(e));
+    };
+    alloc(&c->u, bytes); alloc(&c->g, bytes); alloc(&c->q, bytes);
+    alloc(&c->d[0], bytes); alloc(&c->d[1], bytes);
+    alloc(&c->partials, 2 * (size_t)c->npart * sizeof(double));
+    alloc(&c->strict_slot, 256);
+    alloc(reinterpret_cast<double **>(&c->sc), sizeof(Scalars));
+    for (int b = 0; b < 2; ++b)
+        for (int s = 0; s < 2; ++s) alloc(&c->halo_d[b][s], (size_t)G * sizeof(double));
+    alloc(&c->halo_g[0], (size_t)G * sizeof(double));
+    alloc(&c->halo_g[1], (size_t)G * sizeof(double));
+    if (rc == CG_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(CG_ERR_HIP, "hipStreamCreate failed");
+    if (rc == CG_OK && hipHostMalloc(reinterpret_cast<void **>(&c->host_sc), sizeof(Scalars), hipHostMallocDefault) != hipSuccess)
+        rc = fail(CG_ERR_HIP, "hipHostMalloc failed");
+    if (rc != CG_OK) { cg_destroy(c); return rc; }
+    (void)hipMemset(c->sc, 0, sizeof(Scalars));
+    *out = c;
+    return CG_OK;
+}
+
+int cg_destroy(cg_ctx *c)
+{
+    if (!c) return CG_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
+    delete c->comm;
+    (void)hipFree(c->u); (void)hipFree(c->g); (void)hipFree(c->q);
+    (void)hipFree(c->d[0]); (void)hipFree(c->d[1]);
+    (void)hipFree(c->partials); (void)hipFree(c->strict_slot); (void)hipFree(c->sc); (void)hipFree(c->hist);
+    for (int b = 0; b < 2; ++b)
+        for (int s = 0; s < 2; ++s) (void)hipFree(c->halo_d[b][s]);
+    (void)hipFree(c->halo_g[0]); (void)hipFree(c->halo_g[1]);
+    if (c->host_sc) (void)hipHostFree(c->host_sc);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return CG_OK;
+}
+
+int cg_set_option(cg_ctx *c, int key, long value)
+{
+    if (!c) return fail(CG_ERR_ARG, "cg_set_option: ctx is NULL");
+    switch (key) {
+    case CG_OPT_REDUCE:
+        if (value != CG_REDUCE_FAST && value != CG_REDUCE_STRICT) return fail(CG_ERR_ARG, "unknown reduction order %ld", value);
+        c->reduce = (int)value; break;
+    case CG_OPT_SCHEDULE:
+        if (value < -1 || value > CG_SCHED_FUSED_NOQ) return fail(CG_ERR_ARG, "unknown schedule %ld", value);
+        c->schedule = (int)value; break;
+    case CG_OPT_TILE_H:
+        if (value < 0) return fail(CG_ERR_ARG, "tile height must be >= 0");
+        c->tile_h = value; break;
+    case CG_OPT_GRAPH_ITERS:
+        if (value < 0) return fail(CG_ERR_ARG, "graph length must be >= 0");
+        c->graph_iters = value; break;
+    case CG_OPT_XCD_REMAP: c->remap = value ? 1 : 0; break;
+    case CG_OPT_FLAT_BLOCKS:
+        if (value < 0 || value > (1 << 20)) return fail(CG_ERR_ARG, "flat block count out of range");
+        c->flat_blocks_opt = value; break;
+    default: return fail(CG_ERR_ARG, "unknown option key %d", key);
+    }
+    drop_graph(c);
+    return CG_OK;
+}
+
+int cg_init_problem(cg_ctx *c)
+{
+    if (!c) return fail(CG_ERR_ARG, "cg_init_problem: ctx is NULL");
+    CGCHK(select_device(c->device));
+    hipStream_t s = c->stream;
+    const double h = (double)1 / (double)c->n;           // utils.c:323
+    const size_t bytes = (size_t)c->count * sizeof(double);
+    c->dcur = 0;
+    c->pending_dupdate = false;
+    c->q_valid = true;
+    HIPCHK(hipMemsetAsync(c->u, 0, bytes, s));           // calloc, cg.c:44
+    HIPCHK(hipMemsetAsync(c->q, 0, bytes, s));           // calloc, cg.c:45
+    const int fb = flat_blocks(c->count, 0);
+    hipLaunchKernelGGL(cg::k_init_d, dim3(fb), dim3(kBlock), 0, s, c->d[0], c->G, c->row0, c->rows, h);
+    hipLaunchKernelGGL(cg::k_init_g, dim3(fb), dim3(kBlock), 0, s, c->g, c->d[0], c->count);
+    // Halo rows of d0 are a closed form of the global row index: no exchange needed.
+    const int hb = flat_blocks(c->G, 0);
+    if (c->has_top()) hipLaunchKernelGGL(cg::k_init_d, dim3(hb), dim3(kBlock), 0, s, c->halo_d[0][0], c->G, c->row0 - 1, 1L, h);
+    if (c->has_bot()) hipLaunchKernelGGL(cg::k_init_d, dim3(hb), dim3(kBlock), 0, s, c->halo_d[0][1], c->G, c->row0 + c->rows, 1L, h);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->sc, 0, sizeof(Scalars), s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CG_OK;
+}
+
+int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
+{
+    if (!c || !out) return fail(CG_ERR_ARG, "cg_solve: NULL argument");
+    if (max_iters < 0 || rtol < 0) return fail(CG_ERR_ARG, "cg_solve: max_iters and rtol must be >= 0");
+    CGCHK(select_device(c->device));
+    const int sched = c->effective_schedule();
+    if (c->reduce == CG_REDUCE_STRICT && sched != CG_SCHED_CLASSIC)
+        return fail(CG_ERR_STATE, "strict reduction order needs the CLASSIC schedule (q must be stored)");
+    if (c->nranks > 1 && !c->comm) return fail(CG_ERR_STATE, "multi-rank context without cg_comm_init");
+    hipStream_t s = c->stream;
+
+    // history buffer (set-up, outside the timed region)
+    if (c->hist_cap < max_iters) {
+        drop_graph(c);                                  // the graph's k_finish nodes hold the old pointer
+        (void)hipFree(c->hist); c->hist = nullptr; c->hist_cap = 0;
+        if (max_iters > 0) {
+            HIPCHK(hipMalloc(&c->hist, (size_t)max_iters * sizeof(double)));
+            c->hist_cap = max_iters;
+        }
+    }
+    // graph of the steady-state iteration body (set-up, outside the timed region)
+    long glen = c->graph_iters;
+    if (glen > 0 && max_iters - 1 >= glen) {
+        if (!c->graph || c->graph_sched != sched || c->graph_reduce != c->reduce || c->graph_dcur != c->dcur)
+            CGCHK(build_graph(c, glen));
+    } else {
+        glen = 0;
+    }
+    if (c->graph) glen = c->graph_len;
+    HIPCHK(hipStreamSynchronize(s));
+
+    const auto t0 = std::chrono::steady_clock::now();
+    // q0 = g.g (cg.c:55)
+    {
+        const TileGeom t = ctx_geom(c);
+        const int fb = flat_blocks(c->count / t.vec, c->flat_blocks_opt);
+        if (c->reduce != CG_REDUCE_STRICT) {
+            if (t.vec == 2) hipLaunchKernelGGL(cg::k_dot_partial<2>, dim3(fb), dim3(kBlock), 0, s, c->g, c->g, c->count, c->partials);
+            else hipLaunchKernelGGL(cg::k_dot_partial<1>, dim3(fb), dim3(kBlock), 0, s, c->g, c->g, c->count, c->partials);
+            HIPCHK(hipGetLastError());
+        }
+        CGCHK(enqueue_dot_finish(c, c->g, c->g, c->partials, fb, 2, rtol));
+    }
+    long launched = 0;
+    bool stopped = false;
+    // Iteration 0 runs eagerly: the fused schedules have no d update to fold in yet.
+    if (max_iters > 0) { CGCHK(enqueue_iteration(c, true)); launched = 1; }
+    while (launched < max_iters && !stopped) {
+        if (glen > 0 && max_iters - launched >= glen) {
+            HIPCHK(hipGraphLaunch(c->graph, s));
+            launched += glen;
+        } else {
+            CGCHK(enqueue_iteration(c, false));
+            launched += 1;
+        }
+        if (rtol > 0 && (launched % 64 < (glen > 0 ? glen : 1))) {
+            // Stop rule: look at the device flag now and then.  Iterations launched
+            // after it fired are no-ops on the device, so polling lazily costs
+            // nothing but empty launches.
+            HIPCHK(hipMemcpyAsync(c->host_sc, c->sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            stopped = c->host_sc->done != 0;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->host_sc, c->sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();
+
+    const Scalars &h = *c->host_sc;
+    // Fused schedules flip d's buffers once per executed iteration after the first;
+    // iterations skipped because the stop rule fired did not flip anything.
+    if (sched != CG_SCHED_CLASSIC) {
+        const long executed = (long)h.iter;
+        c->dcur = (executed >= 1) ? (int)((executed - 1) & 1) : 0;
+        c->pending_dupdate = executed >= 1;
+        CGCHK(flush_pending_dupdate(c));
+        HIPCHK(hipStreamSynchronize(s));
+        c->q_valid = (sched == CG_SCHED_FUSED);
+    }
+    c->hist_len = (long)h.iter < c->hist_cap ? (long)h.iter : c->hist_cap;
+    out->iters = (long)h.iter;
+    out->q1 = h.q1;
+    out->q_init = h.q_init;
+    out->seconds = std::chrono::duration<double>(t1 - t0).count();
+    out->converged = h.done;
+    return CG_OK;
+}
+
+int cg_device_ptr(cg_ctx *c, int which, double **out)
+{
+    if (!c || !out) return fail(CG_ERR_ARG, "cg_device_ptr: NULL argument");
+    switch (which) {
+    case CG_VEC_U: *out = c->u; break;
+    case CG_VEC_G: *out = c->g; break;
+    case CG_VEC_D: *out = c->d[c->dcur]; break;
+    case CG_VEC_Q: *out = c->q; break;
+    default: return fail(CG_ERR_ARG, "unknown vector id %d", which);
+    }
+    return CG_OK;
+}
+
+int cg_copy_out(cg_ctx *c, int which, double *host_dst, long count)
+{
+    if (!c || !host_dst) return fail(CG_ERR_ARG, "cg_copy_out: NULL argument");
+    if (count != c->count) return fail(CG_ERR_ARG, "cg_copy_out: count %ld != block size %ld", count, c->count);
+    CGCHK(select_device(c->device));
+    if (which == CG_VEC_Q && !c->q_valid)
+        return fail(CG_ERR_STATE, "q is not stored by the FUSED_NOQ schedule; use CLASSIC or FUSED to read it");
+    double *src;
+    CGCHK(cg_device_ptr(c, which, &src));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(host_dst, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return CG_OK;
+}
+
+int cg_get_history(cg_ctx *c, double *host_dst, long count, long *written)
+{
+    if (!c || !host_dst || count < 0) return fail(CG_ERR_ARG, "cg_get_history: bad arguments");
+    CGCHK(select_device(c->device));
+    const long m = count < c->hist_len ? count : c->hist_len;
+    if (m > 0) HIPCHK(hipMemcpy(host_dst, c->hist, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+    if (written) *written = m;
+    return CG_OK;
+}
+
+int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double *bytes_per_launch)
+{
+    if (!c || !ms_per_launch || reps < 1) return fail(CG_ERR_ARG, "cg_time_kernel: bad arguments");
+    if (c->nranks > 1) return fail(CG_ERR_STATE, "cg_time_kernel is single-GPU only");
+    CGCHK(select_device(c->device));
+    const int sched = c->effective_schedule();
+    const TileGeom t = ctx_geom(c);
+    hipStream_t s = c->stream;
+    const long nvec = c->count / t.vec;
+    const int fb = flat_blocks(nvec, c->flat_blocks_opt);
+    // Give the prologue scalars harmless values: tau = 0 and beta = 1 keep the data bounded.
+    Scalars hs;
+    memset(&hs, 0, sizeof hs);
+    hs.q0 = 1.0; hs.tau = 0.0; hs.beta = 1.0;
+    HIPCHK(hipMemcpy(c->sc, &hs, sizeof hs, hipMemcpyHostToDevice));
+    double per_point = 0.0;
+    auto launch = [&]() {
+        if (which == 0) {
+            StencilArgs a = base_args(c, t);
+            a.partials = c->partials; a.q = c->q;
+            if (sched == CG_SCHED_CLASSIC) {
+                a.d_in = c->d[c->dcur];
+                launch_stencil<0, true>(t, a, s);
+            } else {
+                a.d_in = c->d[c->dcur]; a.g = c->g; a.d_out = c->d[c->dcur ^ 1];
+                if (sched == CG_SCHED_FUSED) launch_stencil<1, true>(t, a, s);
+                else launch_stencil<1, false>(t, a, s);
+                c->dcur ^= 1;
+            }
+        } else if (which == 1) {
+            if (sched == CG_SCHED_FUSED_NOQ) {
+                StencilArgs b = base_args(c, t);
+                b.d_in = c->d[c->dcur]; b.u = c->u; b.gw = c->g; b.partials = c->partials + c->npart;
+                launch_stencil<2, false>(t, b, s);
+            } else if (t.vec == 2) {
+                hipLaunchKernelGGL(cg::k_update<2>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, c->partials + c->npart);
+            } else {
+                hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, c->partials + c->npart);
+            }
+        } else {
+            if (t.vec == 2) hipLaunchKernelGGL(cg::k_dupdate<2>, dim3(fb), dim3(kBlock), 0, s, c->d[c->dcur], c->g, c->count, c->sc, 0);
+            else hipLaunchKernelGGL(cg::k_dupdate<1>, dim3(fb), dim3(kBlock), 0, s, c->d[c->dcur], c->g, c->count, c->sc, 0);
+        }
+    };
+    if (which == 0) per_point = sched == CG_SCHED_CLASSIC ? 16.0 : (sched == CG_SCHED_FUSED ? 32.0 : 24.0);
+    else if (which == 1) per_point = sched == CG_SCHED_FUSED_NOQ ? 40.0 : 48.0;
+    else if (which == 2) {
+        if (sched != CG_SCHED_CLASSIC) return fail(CG_ERR_STATE, "the fused schedules have no separate d-update kernel");
+        per_point = 24.0;
+    } else return fail(CG_ERR_ARG, "unknown kernel id %d", which);
+
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    launch(); launch();                                   // warm-up
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) launch();
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / reps;
+    if (bytes_per_launch) *bytes_per_launch = per_point * (double)c->count;
+    return CG_OK;
+}
+
+// ------------------------------------------------------------- multi-GPU ---
+
+int cg_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(CG_ERR_ARG, "cg_comm_unique_id: NULL");
+    char msg[256];
+    if (cg::Comm::unique_id(id128, msg, sizeof msg) != 0) return fail(CG_ERR_COMM, "%s", msg);
+    return CG_OK;
+}
+
+int cg_comm_init(cg_ctx *c, const void *id128)
+{
+    if (!c || !id128) return fail(CG_ERR_ARG, "cg_comm_init: NULL argument");
+    if (c->nranks < 2) return fail(CG_ERR_STATE, "cg_comm_init on a single-rank context");
+    CGCHK(select_device(c->device));
+    delete c->comm;
+    c->comm = nullptr;
+    char msg[256];
+    cg::Comm *comm = cg::Comm::create(id128, c->rank, c->nranks, c->has_top(), c->has_bot(), msg, sizeof msg);
+    if (!comm) return fail(CG_ERR_COMM, "%s", msg);
+    c->comm = comm;
+    drop_graph(c);
+    return CG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,197 @@
+"""Host-side mirror of the CG hot path: thin Python objects over the C ABI.
+
+`CGSolver` is the body of the reference's main() between set-up and output
+(cg.c:41-134) with the vectors resident in HBM; `DeviceVector` plus the
+module-level functions mirror the stand-alone operators (apply_stencil_serial,
+dot, the three update loops) on caller-owned device arrays.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import lib as _l
+
+
+@dataclass
+class SolveResult:
+    iters: int
+    q1: float            # last g.g, the reference's "norm_g^2" (cg.c:139)
+    q_init: float        # g0.g0 (cg.c:55)
+    seconds: float       # the reference's timed region (cg.c:50-51,131-132)
+    converged: bool
+
+
+class DeviceVector:
+    """`count` doubles in the HBM of `device` (zero-filled, like calloc at cg.c:44-45)."""
+
+    def __init__(self, count, device=0):
+        self.count, self.device = int(count), int(device)
+        p = C.c_void_p()
+        _l.check(_l.load().cg_malloc(self.device, self.count, C.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, arr, device=0):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        v = cls(a.size, device)
+        _l.check(_l.load().cg_copy_to_device(device, v.ptr, a.ctypes.data_as(C.c_void_p), a.size))
+        return v
+
+    def to_host(self):
+        out = np.empty(self.count, dtype=np.float64)
+        _l.check(_l.load().cg_copy_to_host(self.device, out.ctypes.data_as(C.c_void_p), self.ptr, self.count))
+        return out
+
+    def offset(self, elems):
+        """Device pointer `elems` doubles into the vector."""
+        return C.c_void_p(self.ptr.value + 8 * int(elems))
+
+    def free(self):
+        if self.ptr:
+            _l.load().cg_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _p(x):
+    if x is None:
+        return None
+    return x.ptr if isinstance(x, DeviceVector) else x
+
+
+def init_d(n, row0, rows, d, device=0):
+    """d0 on global rows [row0, row0+rows): init_locald's fill loop (utils.c:319-337)."""
+    _l.check(_l.load().cg_init_d(device, n, row0, rows, _p(d)))
+
+
+def init_g(count, d, g, device=0):
+    """g0 = -d0: init_localg (utils.c:342-350)."""
+    _l.check(_l.load().cg_init_g(device, count, _p(d), _p(g)))
+
+
+def stencil(G, row0, rows, d, q, top=None, bot=None, device=0, want_dq=False):
+    """q = A d on a row block: apply_stencil_serial / the row part of apply_stencil_parallel."""
+    dq = C.c_double(0.0)
+    _l.check(_l.load().cg_stencil(device, G, row0, rows, _p(d), _p(top), _p(bot), _p(q),
+                                  C.byref(dq) if want_dq else None))
+    return dq.value if want_dq else None
+
+
+def dot(count, v, w, strict=False, start=0.0, device=0):
+    """sum v[k]*w[k]: the local part of dot (utils.c:368-379)."""
+    r = C.c_double(0.0)
+    _l.check(_l.load().cg_dot(device, count, _p(v), _p(w), 1 if strict else 0, start, C.byref(r)))
+    return r.value
+
+
+def axpy(count, a, x, y, device=0):
+    """y += a*x (cg.c:63-76)."""
+    _l.check(_l.load().cg_axpy(device, count, a, _p(x), _p(y)))
+
+
+def xpay(count, b, d, g, device=0):
+    """d = b*d - g (cg.c:81-87)."""
+    _l.check(_l.load().cg_xpay(device, count, b, _p(d), _p(g)))
+
+
+class CGSolver:
+    """One row block of the CG solve on one GPU.
+
+    Single GPU: CGSolver(n).  Multi-GPU: rank r of P owns rows
+    [r*G/P, (r+1)*G/P) and calls comm_init with the id rank 0 generated.
+    """
+
+    def __init__(self, n, device=0, row0=0, rows=None, rank=0, nranks=1):
+        self.n, self.G = int(n), int(n) + 1
+        self.device, self.rank, self.nranks = int(device), int(rank), int(nranks)
+        self.row0 = int(row0)
+        self.rows = self.G if rows is None else int(rows)
+        self.count = self.rows * self.G
+        self._lib = _l.load()
+        ctx = C.c_void_p()
+        _l.check(self._lib.cg_create(C.byref(ctx), self.device, self.n, self.row0, self.rows, self.rank, self.nranks))
+        self._ctx = ctx
+        self.reduce, self.schedule = _l.REDUCE_FAST, _l.SCHED_FUSED_NOQ
+
+    # -- configuration ---------------------------------------------------
+    def set_option(self, key, value):
+        _l.check(self._lib.cg_set_option(self._ctx, key, int(value)))
+
+    def configure(self, reduce=None, schedule=None, tile_h=None, graph_iters=None, xcd_remap=None,
+                  flat_blocks=None):
+        if reduce is not None:
+            self.set_option(_l.OPT_REDUCE, reduce)
+            self.reduce = reduce
+            if schedule is None and reduce == _l.REDUCE_STRICT:
+                schedule = _l.SCHED_CLASSIC
+        if schedule is not None:
+            self.set_option(_l.OPT_SCHEDULE, schedule)
+            self.schedule = schedule
+        if tile_h is not None:
+            self.set_option(_l.OPT_TILE_H, tile_h)
+        if graph_iters is not None:
+            self.set_option(_l.OPT_GRAPH_ITERS, graph_iters)
+        if xcd_remap is not None:
+            self.set_option(_l.OPT_XCD_REMAP, 1 if xcd_remap else 0)
+        if flat_blocks is not None:
+            self.set_option(_l.OPT_FLAT_BLOCKS, flat_blocks)
+        return self
+
+    @property
+    def bytes_per_point(self):
+        return _l.SCHED_BYTES_PER_POINT[self.schedule]
+
+    # -- multi-GPU -------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        _l.check(_l.load().cg_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, id128):
+        buf = C.create_string_buffer(bytes(id128), 128)
+        _l.check(self._lib.cg_comm_init(self._ctx, buf))
+
+    # -- solve -----------------------------------------------------------
+    def init_problem(self):
+        _l.check(self._lib.cg_init_problem(self._ctx))
+        return self
+
+    def solve(self, max_iters=200, rtol=0.0):
+        r = _l.Result()
+        _l.check(self._lib.cg_solve(self._ctx, int(max_iters), float(rtol), C.byref(r)))
+        return SolveResult(r.iters, r.q1, r.q_init, r.seconds, bool(r.converged))
+
+    def vector(self, which):
+        out = np.empty(self.count, dtype=np.float64)
+        _l.check(self._lib.cg_copy_out(self._ctx, which, out.ctypes.data_as(C.c_void_p), self.count))
+        return out.reshape(self.rows, self.G)
+
+    def history(self, count):
+        out = np.empty(max(int(count), 1), dtype=np.float64)
+        n = C.c_long(0)
+        _l.check(self._lib.cg_get_history(self._ctx, out.ctypes.data_as(C.c_void_p), int(count), C.byref(n)))
+        return out[:n.value].copy()
+
+    def time_kernel(self, which, reps=20):
+        """(mean ms per launch, algorithmic bytes per launch) of one hot-path kernel, HIP-event timed."""
+        ms, nbytes = C.c_double(0.0), C.c_double(0.0)
+        _l.check(self._lib.cg_time_kernel(self._ctx, int(which), int(reps), C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.cg_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

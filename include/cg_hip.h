@@ -1,0 +1,150 @@
+/*
+ * C ABI of the MI355X (gfx950) conjugate-gradient hot path: libcg_hip.so.
+ *
+ * Plain C linkage, plain pointers and sizes.  Every `double *` that is not
+ * explicitly called a host pointer is a DEVICE pointer (HBM of the GPU the
+ * context or the call is bound to).  Every function returns 0 on success and a
+ * negative code on failure; cg_last_error() gives the text.  Nothing here falls
+ * back to the CPU: without a GPU every compute entry point fails.
+ *
+ * Each entry point cites the piece of the reference (omarmalik710/
+ * conjugate-gradient, files cg.c / utils.c / utils.h) that it replaces.  The
+ * reference keeps the vectors in host memory and runs the update loops inline
+ * in main(); here the vectors live in HBM, so everything that touches them --
+ * allocation, the three update loops, the scalar recurrences, the read-back --
+ * sits behind this interface.  include/utils.h re-exports the reference's own
+ * nine names on top of it.
+ */
+#ifndef CG_HIP_H
+#define CG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status ------------------------------------------------------------- */
+#define CG_OK              0
+#define CG_ERR_HIP        -1   /* a HIP runtime call failed                      */
+#define CG_ERR_ARG        -2   /* bad argument (shape, alignment, null pointer)  */
+#define CG_ERR_STATE      -3   /* call not valid in the context's current state  */
+#define CG_ERR_NOGPU      -4   /* no usable gfx950 device                        */
+#define CG_ERR_COMM       -5   /* RCCL could not be loaded or a call failed      */
+
+const char *cg_last_error(void);          /* thread-local text of the last failure  */
+int cg_device_count(int *count);          /* number of visible HIP devices          */
+
+/* ---- raw device memory, so that C callers need not link HIP --------------
+ * Replaces the malloc/calloc/free of the vectors in main (cg.c:44-45,143-145)
+ * and in init_locald / init_localg (utils.c:278,343).                        */
+int cg_malloc(int device, long count, double **out);     /* count doubles, zero-filled (calloc, cg.c:44-45) */
+int cg_free(int device, double *p);
+int cg_copy_to_host(int device, double *host_dst, const double *dev_src, long count);
+int cg_copy_to_device(int device, double *dev_dst, const double *host_src, long count);
+
+/* ---- stand-alone operators on caller-owned device arrays -----------------
+ * All run on `device`'s internal stream and are complete when they return.  */
+
+/* d0 for global rows [row0, row0+rows) of the (n+1)^2 grid, all n+1 columns.
+ * Replaces the fill loop of init_locald, utils.c:319-337.                    */
+int cg_init_d(int device, long n, long row0, long rows, double *d);
+/* g0 = -d0.  Replaces init_localg, utils.c:342-350.                          */
+int cg_init_g(int device, long count, const double *d, double *g);
+/* q = A d on a block of `rows` full rows of a G x G grid that starts at
+ * global row row0; top/bot = the rows just outside the block (device
+ * pointers, NULL at the global boundary).  Global boundary points of q are
+ * not written.  Replaces apply_stencil_serial (utils.c:8-36) and the row part
+ * of apply_stencil_parallel (utils.c:38-104).  If dq_host != NULL it also
+ * returns d.q accumulated in the fast order (fused, one pass).               */
+int cg_stencil(int device, long G, long row0, long rows, const double *d,
+               const double *top, const double *bot, double *q, double *dq_host);
+/* *result_host = sum v[k]*w[k], k = 0..count-1.  strict = 1: one accumulator in
+ * index order starting from `start` (bit-identical to utils.c:372-379);
+ * strict = 0: the documented fast order (start is added last).
+ * Replaces the local part of dot, utils.c:368-379.                           */
+int cg_dot(int device, long count, const double *v, const double *w, int strict,
+           double start, double *result_host);
+/* y[k] += a*x[k].  Replaces the loops at cg.c:63-76.                         */
+int cg_axpy(int device, long count, double a, const double *x, double *y);
+/* d[k] = b*d[k] - g[k].  Replaces the loop at cg.c:81-87.                    */
+int cg_xpay(int device, long count, double b, double *d, const double *g);
+
+/* ---- whole-solve context -------------------------------------------------
+ * Replaces the body of main between set-up and output (cg.c:41-134).         */
+typedef struct cg_ctx cg_ctx;
+
+/* Reduction order of the dot products. */
+#define CG_REDUCE_FAST    0    /* wavefront shuffle -> workgroup -> fixed-order grid sum */
+#define CG_REDUCE_STRICT  1    /* one accumulator, index order: bit-identical to the reference */
+/* Kernel schedule of one iteration (all produce bit-identical vectors). */
+#define CG_SCHED_CLASSIC  0    /* stencil+d.q | u,g update+g.g | d update        : 88 B/point */
+#define CG_SCHED_FUSED    1    /* d update fused into the stencil kernel         : 80 B/point */
+#define CG_SCHED_FUSED_NOQ 2   /* ... and q recomputed in the update kernel      : 64 B/point */
+
+/* Option keys for cg_set_option. */
+#define CG_OPT_REDUCE      1   /* CG_REDUCE_*                        default FAST     */
+#define CG_OPT_SCHEDULE    2   /* CG_SCHED_*                         default FUSED_NOQ (CLASSIC when strict) */
+#define CG_OPT_TILE_H      3   /* rows per stencil tile, 0 = auto                     */
+#define CG_OPT_GRAPH_ITERS 4   /* iterations captured per hipGraph, 0 = no graph; default 10 */
+#define CG_OPT_XCD_REMAP   5   /* 1 = XCD-aware tile order (default), 0 = plain order  */
+#define CG_OPT_FLAT_BLOCKS 6   /* workgroups of the flat (1-D) kernels, 0 = auto       */
+
+/* A context owns the row block [row0, row0+rows) x (n+1) of u, g, d, q on
+ * `device`.  Single GPU: row0 = 0, rows = n+1, rank 0 of 1.                  */
+int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks);
+int cg_destroy(cg_ctx *ctx);
+int cg_set_option(cg_ctx *ctx, int key, long value);
+
+/* u = 0, q = 0, d = d0, g = -d0 (cg.c:41-45 via utils.c:276-350).            */
+int cg_init_problem(cg_ctx *ctx);
+
+typedef struct cg_result {
+    long iters;          /* iterations executed                                  */
+    double q1;           /* last g.g: the reference's "norm_g^2" (cg.c:139)      */
+    double q_init;       /* g0.g0 (cg.c:55)                                      */
+    double seconds;      /* wall time of the reference's timed region
+                            (cg.c:50-51,131-132): initial g.g + all iterations,
+                            device-synchronised at both ends                     */
+    int converged;       /* 1 if the stop rule fired                             */
+} cg_result;
+
+/* Run at most max_iters iterations from the context's current state (call
+ * cg_init_problem first).  rtol > 0 adds the stop rule q1 <= rtol^2 * q_init,
+ * evaluated on the device after every iteration; the vectors are left exactly
+ * as they were when it fired.  rtol = 0 is the reference's fixed count.      */
+int cg_solve(cg_ctx *ctx, long max_iters, double rtol, cg_result *out);
+
+#define CG_VEC_U 0
+#define CG_VEC_G 1
+#define CG_VEC_D 2
+#define CG_VEC_Q 3
+/* Copy one of the context's vectors (rows*(n+1) doubles) to host memory.     */
+int cg_copy_out(cg_ctx *ctx, int which, double *host_dst, long count);
+/* Device pointer of one of the context's vectors (valid until cg_destroy or
+ * the next cg_solve, which may swap d's two buffers).                        */
+int cg_device_ptr(cg_ctx *ctx, int which, double **out);
+/* q1 of every iteration of the last solve (host pointer, up to `count`).     */
+int cg_get_history(cg_ctx *ctx, double *host_dst, long count, long *written);
+
+/* ---- measurement ----------------------------------------------------------
+ * Time `reps` back-to-back launches of one hot-path kernel of the context's
+ * current schedule with HIP events on the context's own stream.
+ * which: 0 = stencil kernel (as scheduled: with the fused d-update if any),
+ *        1 = update kernel, 2 = d-update kernel (CLASSIC only).
+ * Outputs the mean milliseconds per launch and the algorithmic bytes one
+ * launch moves (the per-point figure of the schedule times the block's points).
+ * The vectors are modified; re-initialise before solving again.              */
+int cg_time_kernel(cg_ctx *ctx, int which, int reps, double *ms_per_launch, double *bytes_per_launch);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------
+ * Replaces init_mpi_settings (utils.c:383-420), exchange_boundaries
+ * (utils.c:221-274, rows only) and the MPI_Allreduce in dot (utils.c:380).
+ * Rank r owns rows [r*G/P, (r+1)*G/P).  The 128-byte id comes from rank 0's
+ * cg_comm_unique_id and reaches the other ranks through any host channel
+ * (torch.distributed / MPI broadcast).                                       */
+int cg_comm_unique_id(void *id128);
+int cg_comm_init(cg_ctx *ctx, const void *id128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+/*
+ * CPU oracle for the fp64 CG hot path -- TEST INFRASTRUCTURE ONLY (see
+ * cg_oracle.h for the rules on who may call it and how parity is pinned).
+ *
+ * Build: gcc -std=c99 -O2 -ffp-contract=off  (no -ffast-math; -std=c99 alone
+ * already disables contraction in GCC, the flag is given for clarity and for
+ * clang).  64-bit indices throughout, so grids beyond 46340^2 are fine.
+ */
+#include "cg_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* utils.c:319-337.  h = (double)1/n (:323); the coordinate of a row/column is
+ * index*h with the index converted from an integer (:325,:327); the value is
+ * 2*h*h * ( xi*(1-xi) + yj*(1-yj) ) evaluated left to right (:334); points on
+ * the global boundary are exactly 0.0 (:329-331). */
+void oracle_init_d(long n, long row0, long rows, double *d)
+{
+    const long G = n + 1;
+    const double h = (double)1 / (double)n;
+    for (long r = 0; r < rows; ++r) {
+        const long gi = row0 + r;
+        const double xi = (double)gi * h;
+        double *row = d + r * G;
+        for (long j = 0; j < G; ++j) {
+            if (gi == 0 || gi == G - 1 || j == 0 || j == G - 1) {
+                row[j] = 0.0;
+            } else {
+                const double yj = (double)j * h;
+                row[j] = 2 * h * h * (xi * (1 - xi) + yj * (1 - yj));
+            }
+        }
+    }
+}
+
+/* utils.c:342-350 (boundary entries become -0.0, as in the reference). */
+void oracle_init_g(long count, const double *d, double *g)
+{
+    for (long k = 0; k < count; ++k) g[k] = -d[k];
+}
+
+/* One stencil point; the five terms are added to a zero-initialised
+ * accumulator in the order up, left, centre, right, down (utils.c:25-31).
+ * The integer coefficients -1 and 4 are converted to double per use. */
+static inline double stencil_point(double up, double left, double centre,
+                                   double right, double down)
+{
+    double acc = 0;
+    acc += (double)(-1) * up;
+    acc += (double)(-1) * left;
+    acc += (double)(4) * centre;
+    acc += (double)(-1) * right;
+    acc += (double)(-1) * down;
+    return acc;
+}
+
+/* utils.c:15-35 for rows whose neighbours are inside the block, utils.c:74-104
+ * for the first/last row of a block that has a halo row. */
+void oracle_stencil(long G, long row0, long rows, const double *d,
+                    const double *top, const double *bot, double *q)
+{
+    for (long r = 0; r < rows; ++r) {
+        const long gi = row0 + r;
+        if (gi == 0 || gi == G - 1) continue;          /* Dirichlet rows: untouched */
+        const double *cur = d + r * G;
+        const double *up = (r > 0) ? cur - G : top;
+        const double *down = (r < rows - 1) ? cur + G : bot;
+        double *out = q + r * G;
+        for (long j = 1; j < G - 1; ++j)
+            out[j] = stencil_point(up[j], cur[j - 1], cur[j], cur[j + 1], down[j]);
+    }
+}
+
+/* utils.c:372-379: the N%4 remainder is summed first over k = 0..rem-1 and
+ * the unrolled loop continues from there, every product being added to the
+ * one accumulator in turn -- i.e. a plain sequential sum in index order. */
+double oracle_dot_from(double start, long count, const double *v, const double *w)
+{
+    double acc = start;
+    for (long k = 0; k < count; ++k) acc += v[k] * w[k];
+    return acc;
+}
+
+double oracle_dot(long count, const double *v, const double *w)
+{
+    return oracle_dot_from(0.0, count, v, w);
+}
+
+/* cg.c:63-76: y[k] += a*x[k], product rounded before the add. */
+void oracle_axpy(long count, double a, const double *x, double *y)
+{
+    for (long k = 0; k < count; ++k) {
+        const double t = a * x[k];
+        y[k] = y[k] + t;
+    }
+}
+
+/* cg.c:81-87: d[k] = b*d[k] - g[k], product rounded before the subtract. */
+void oracle_xpay(long count, double b, double *d, const double *g)
+{
+    for (long k = 0; k < count; ++k) {
+        const double t = b * d[k];
+        d[k] = t - g[k];
+    }
+}
+
+/* cg.c:41-45 (set-up) and cg.c:55-90 (loop). */
+long oracle_cg(long n, long max_iters, double rtol,
+               double *u, double *g, double *d, double *q,
+               double *q1_hist, double *q_init)
+{
+    const long G = n + 1;
+    const long N = G * G;
+    oracle_init_d(n, 0, G, d);
+    oracle_init_g(N, d, g);
+    memset(u, 0, (size_t)N * sizeof(double));
+    memset(q, 0, (size_t)N * sizeof(double));
+
+    double q0 = oracle_dot(N, g, g);                       /* cg.c:55 */
+    if (q_init) *q_init = q0;
+    const double stop = rtol * rtol * q0;
+    long it = 0;
+    for (; it < max_iters; ++it) {
+        oracle_stencil(G, 0, G, d, NULL, NULL, q);         /* cg.c:58 */
+        double tau = oracle_dot(N, d, q);                  /* cg.c:61 */
+        tau = q0 / tau;                                    /* cg.c:62 */
+        oracle_axpy(N, tau, d, u);                         /* cg.c:63-69 */
+        oracle_axpy(N, tau, q, g);                         /* cg.c:70-76 */
+        const double q1 = oracle_dot(N, g, g);             /* cg.c:79 */
+        const double beta = q1 / q0;                       /* cg.c:80 */
+        oracle_xpay(N, beta, d, g);                        /* cg.c:81-87 */
+        q0 = q1;                                           /* cg.c:89 */
+        if (q1_hist) q1_hist[it] = q1;
+        if (rtol > 0 && q1 <= stop) { ++it; break; }
+    }
+    return it;
+}
+
+/* Row-block form: block b owns global rows [b*G/nblocks, (b+1)*G/nblocks) and
+ * sees one halo row of d on each interior side (the NULL-pad convention of
+ * utils.c:290-301, rows only).  The dot products chain the accumulator through
+ * the blocks in block order, which is the same global index order as the
+ * single-block sum, so every value is bit-identical to oracle_cg. */
+long oracle_cg_rowblocks(long n, long nblocks, long max_iters, double rtol,
+                         double *u, double *g, double *d, double *q,
+                         double *q1_hist, double *q_init)
+{
+    const long G = n + 1;
+    const long N = G * G;
+    if (nblocks < 1 || G % nblocks != 0) return -1;
+    const long R = G / nblocks;
+    double *halo_top = (double *)malloc((size_t)G * sizeof(double));
+    double *halo_bot = (double *)malloc((size_t)G * sizeof(double));
+    if (!halo_top || !halo_bot) { free(halo_top); free(halo_bot); return -1; }
+
+    for (long b = 0; b < nblocks; ++b) oracle_init_d(n, b * R, R, d + b * R * G);
+    oracle_init_g(N, d, g);
+    memset(u, 0, (size_t)N * sizeof(double));
+    memset(q, 0, (size_t)N * sizeof(double));
+
+    double q0 = 0.0;
+    for (long b = 0; b < nblocks; ++b)
+        q0 = oracle_dot_from(q0, R * G, g + b * R * G, g + b * R * G);
+    if (q_init) *q_init = q0;
+    const double stop = rtol * rtol * q0;
+    long it = 0;
+    for (; it < max_iters; ++it) {
+        for (long b = 0; b < nblocks; ++b) {
+            const double *blk = d + b * R * G;
+            const double *top = NULL, *bot = NULL;
+            if (b > 0) { memcpy(halo_top, blk - G, (size_t)G * sizeof(double)); top = halo_top; }
+            if (b < nblocks - 1) { memcpy(halo_bot, blk + R * G, (size_t)G * sizeof(double)); bot = halo_bot; }
+            oracle_stencil(G, b * R, R, blk, top, bot, q + b * R * G);
+        }
+        double dq = 0.0;
+        for (long b = 0; b < nblocks; ++b)
+            dq = oracle_dot_from(dq, R * G, d + b * R * G, q + b * R * G);
+        const double tau = q0 / dq;
+        for (long b = 0; b < nblocks; ++b) {
+            oracle_axpy(R * G, tau, d + b * R * G, u + b * R * G);
+            oracle_axpy(R * G, tau, q + b * R * G, g + b * R * G);
+        }
+        double q1 = 0.0;
+        for (long b = 0; b < nblocks; ++b)
+            q1 = oracle_dot_from(q1, R * G, g + b * R * G, g + b * R * G);
+        const double beta = q1 / q0;
+        for (long b = 0; b < nblocks; ++b)
+            oracle_xpay(R * G, beta, d + b * R * G, g + b * R * G);
+        q0 = q1;
+        if (q1_hist) q1_hist[it] = q1;
+        if (rtol > 0 && q1 <= stop) { ++it; break; }
+    }
+    free(halo_top);
+    free(halo_bot);
+    return it;
+}

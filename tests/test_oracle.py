@@ -1,0 +1,96 @@
+"""The CPU oracle against the reference's own outputs (CPU only).
+
+Every golden record was produced by running the reference's cg.c + utils.c
+(oracle/_ref/cg_ref, see tests/golden/make_golden.py).  The oracle must
+reproduce the single-rank records bit for bit: that is what pins it.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits, golden_arrays, seq_sum
+
+NP1_FIXED = [(15, 10), (20, 12), (63, 50), (100, 30), (256, 200), (255, 200), (511, 100), (1023, 200)]
+
+
+@pytest.mark.parametrize("n,iters", NP1_FIXED)
+def test_oracle_matches_reference_q1_and_sum_u(oracle, golden, n, iters):
+    rec = golden[(n, iters, 1, 0.0)]
+    r = oracle.cg(n, iters)
+    assert r["iters"] == rec["iters"] == iters
+    assert float(r["q1"]).hex() == float.fromhex(rec["q1_hex"]).hex()
+    assert float(r["q_init"]).hex() == float.fromhex(rec["q_init_hex"]).hex()
+    assert float(seq_sum(oracle, r["u"])).hex() == rec["sum_u_hex"]
+
+
+@pytest.mark.parametrize("n,iters", [(15, 10), (20, 12), (63, 50)])
+def test_oracle_matches_reference_arrays_bitwise(oracle, golden, n, iters):
+    rec = golden[(n, iters, 1, 0.0)]
+    want = golden_arrays(rec["arrays"], n)
+    r = oracle.cg(n, iters)
+    for k in ("u", "g", "d"):
+        assert np.array_equal(bits(r[k]), bits(want[k])), k
+
+
+@pytest.mark.parametrize("n", [15, 63, 255])
+def test_oracle_stop_rule_matches_reference(oracle, golden, n):
+    rec = golden[(n, 10000, 1, 1e-8)]
+    r = oracle.cg(n, 10000, rtol=1e-8)
+    assert r["iters"] == rec["iters"]
+    assert float(r["q1"]).hex() == float.fromhex(rec["q1_hex"]).hex()
+    assert float(seq_sum(oracle, r["u"])).hex() == rec["sum_u_hex"]
+
+
+@pytest.mark.parametrize("n,blocks", [(15, 2), (15, 4), (63, 8), (255, 4), (20, 3), (20, 7)])
+def test_rowblock_form_is_bit_identical(oracle, n, blocks):
+    a = oracle.cg(n, 25)
+    b = oracle.cg(n, 25, nblocks=blocks)
+    assert a["iters"] == b["iters"]
+    for k in ("u", "g", "d", "q", "hist"):
+        assert np.array_equal(bits(a[k]), bits(b[k])), k
+
+
+def test_rowblock_rejects_indivisible(oracle):
+    with pytest.raises(ValueError):
+        oracle.cg(15, 5, nblocks=3)
+
+
+def test_first_stencil_closed_form(oracle):
+    # A d0 = 8 h^4 wherever all four neighbours are interior points.
+    n = 64
+    d = oracle.init_d(n)
+    q = oracle.stencil(d)
+    h = 1.0 / n
+    inner = q[2:-2, 2:-2]
+    assert np.allclose(inner, 8 * h ** 4, rtol=1e-9, atol=0)
+    assert np.all(q[0] == 0) and np.all(q[-1] == 0) and np.all(q[:, 0] == 0) and np.all(q[:, -1] == 0)
+
+
+def test_init_values(oracle):
+    n = 20
+    d = oracle.init_d(n)
+    g = oracle.init_g(d)
+    h = 1.0 / n
+    i, j = 3, 7
+    assert d[i, j] == 2 * h * h * ((i * h) * (1 - i * h) + (j * h) * (1 - j * h))
+    assert np.all(d[0] == 0) and np.all(d[:, -1] == 0)
+    assert np.array_equal(bits(g), bits(-d))
+    # row-block initialisation is the same function of the global row index
+    blk = oracle.init_d(n, row0=7, rows=7)
+    assert np.array_equal(bits(blk), bits(d[7:14]))
+
+
+def test_converged_solution_is_the_analytic_one(oracle):
+    # u = x(1-x) y(1-y) has zero fourth derivatives, so the 5-point stencil is exact for it.
+    n = 63
+    r = oracle.cg(n, 10000, rtol=1e-8)
+    x = np.arange(n + 1) / n
+    exact = np.outer(x * (1 - x), x * (1 - x))
+    assert np.max(np.abs(r["u"] - exact)) < 5e-11
+
+
+def test_history_and_stop_semantics(oracle):
+    r = oracle.cg(63, 10000, rtol=1e-8)
+    thr = (1e-8) ** 2 * r["q_init"]
+    assert r["hist"][-1] <= thr
+    assert np.all(r["hist"][:-1] > thr)
+    assert len(r["hist"]) == r["iters"]
