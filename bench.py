@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fp64 CG iterations/sec on the 16384^2 grid (BASELINE.json configs[2]/[3]).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step is one CG iteration (stencil matvec + both dot products + the three
+vector updates) over the whole grid.  N = 1 runs the 16384 x 16384 grid on one
+MI355X; N > 1 (launched by torch.distributed.run, one rank per GPU) row-partitions
+the same grid over the ranks (strong scaling), halo rows and dot products going
+through RCCL inside the library.  Inputs are the reference's own closed-form
+right-hand side (no RNG), generated on the device before the timed region.
+
+Rank 0 prints ONE JSON line.  `value` is whole-job iterations/sec.  `roofline`
+describes the dominant kernel (HIP-event timed on the solver's own stream inside
+this run); `cpu_baseline` is the reference's CPU path timed on this box's host
+cores on a bounded sample (N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+
+
+def cpu_baseline(n, budget_s=40.0):
+    """The reference's CPU path on this box's host cores, bounded sample of the same workload."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "cg_ref")
+    mpirun = "/opt/conda/bin/mpirun"
+    G = n + 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    iters = 5
+    # the reference accepts perfect-square rank counts whose root divides the grid side (cg.c:15,23)
+    for np_ in (64, 16, 4, 1):
+        root = int(round(np_ ** 0.5))
+        if np_ > cores or G % root:
+            continue
+        if not os.path.exists(ref) or (np_ > 1 and not os.path.exists(mpirun)):
+            continue
+        cmd = [ref, str(n)] if np_ == 1 else [mpirun, "-np", str(np_), ref, str(n)]
+        try:
+            out = subprocess.run(cmd, env=dict(os.environ, REF_ITERS=str(iters)), capture_output=True, text=True,
+                                 timeout=budget_s * 4).stdout
+            m = re.search(r"^\s*([0-9]+\.[0-9]+)\s*$", out, flags=re.M)
+            if m and "[ORACLE]" in out:
+                sec = float(m.group(1))
+                return {"value": iters / sec, "unit": "it/s", "cores": np_, "kind": "reference",
+                        "sample": f"{iters} iterations of the {G}x{G} grid, reference cg.c+utils.c, mpirun -np {np_}"}
+        except Exception:
+            pass
+    port = os.path.join(ROOT, "oracle", "cg_oracle")
+    if os.path.exists(port):
+        try:
+            out = subprocess.run([port, str(n), str(iters)], capture_output=True, text=True, timeout=budget_s * 4).stdout
+            m = re.search(r"^\s*([0-9]+\.[0-9]+)\s*$", out, flags=re.M)
+            if m:
+                sec = float(m.group(1))
+                return {"value": iters / sec, "unit": "it/s", "cores": 1, "kind": "port",
+                        "sample": f"{iters} iterations of the {G}x{G} grid, CPU restatement oracle/cg_oracle, 1 thread"}
+        except Exception:
+            pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=16383, help="argv n of the reference: grid side is n+1")
+    ap.add_argument("--schedule", choices=["classic", "fused", "fused_noq"], default="fused_noq")
+    ap.add_argument("--tile-h", type=int, default=0)
+    ap.add_argument("--graph-iters", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    cg = importlib.import_module("conjugate-gradient_amd")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the CG hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, G = args.n, args.n + 1
+    if G % world:
+        raise SystemExit(f"grid side {G} not divisible by {world} ranks")
+    rows = G // world
+    sched = {"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[args.schedule]
+    s = cg.CGSolver(n, device=local_rank, row0=rank * rows, rows=rows, rank=rank, nranks=world)
+    s.configure(reduce=cg.REDUCE_FAST, schedule=sched, tile_h=args.tile_h, graph_iters=args.graph_iters)
+    if world > 1:
+        ids = [cg.CGSolver.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        s.comm_init(ids[0])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    s.init_problem()
+    if args.warmup > 0:
+        s.solve(args.warmup)                 # untimed: also captures the hipGraph
+    fence()
+    t0 = time.perf_counter()
+    res = s.solve(args.steps)                # exactly K iterations, continuing the same solve
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        bpp = s.bytes_per_point
+        its = args.steps / elapsed
+        out = {
+            "metric": "cg_iterations_per_sec", "value": its, "unit": "it/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{G}x{G} fp64 grid, fixed-count CG, 5-point stencil "
+                                   f"(BASELINE.json configs[{2 if world == 1 else 3}])",
+                       "grid": G, "rows_per_gpu": rows, "schedule": args.schedule, "reduce": "fast",
+                       "bytes_per_point_per_iter": bpp, "graph_iters": args.graph_iters,
+                       "parallelism": f"rowblocks{world}"},
+            "hbm_gbs_per_gpu": bpp * rows * G * its / 1e9,
+            "hbm_frac_of_peak": bpp * rows * G * its / 1e9 / HBM_PEAK_GBS,
+            "q1": res.q1, "iters_total": args.warmup + args.steps,
+        }
+    # per-kernel roofline: HIP events on the solver's stream, this run, this GPU
+    if world == 1:
+        kern = {}
+        for which, name in ((0, "stencil"), (1, "update")) + (((2, "dupdate"),) if sched == cg.SCHED_CLASSIC else ()):
+            ms, nbytes = s.time_kernel(which, reps=20)
+            kern[name] = {"ms": ms, "bytes": nbytes, "gbs": nbytes / ms / 1e6}
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": kern[dom]["bytes"], "ms_per_launch": kern[dom]["ms"]}
+        out["kernels"] = kern
+        s.close()
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
