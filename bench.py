@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--schedule", choices=["classic", "fused", "fused_noq"], default="fused_noq")
     ap.add_argument("--tile-h", type=int, default=0)
     ap.add_argument("--graph-iters", type=int, default=10)
+    ap.add_argument("--prefetch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,7 +103,7 @@ def main():
     rows = G // world
     sched = {"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[args.schedule]
     s = cg.CGSolver(n, device=local_rank, row0=rank * rows, rows=rows, rank=rank, nranks=world)
-    s.configure(reduce=cg.REDUCE_FAST, schedule=sched, tile_h=args.tile_h, graph_iters=args.graph_iters)
+    s.configure(reduce=cg.REDUCE_FAST, schedule=sched, tile_h=args.tile_h, graph_iters=args.graph_iters, prefetch=args.prefetch)
     if world > 1:
         ids = [cg.CGSolver.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)

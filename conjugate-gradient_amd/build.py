@@ -41,11 +41,23 @@ def build_driver(force=False, verbose=False):
         return None
     deps = files + [os.path.join(ROOT, "include", "utils.h"), os.path.join(ROOT, "include", "cg_hip.h"), LIB]
     if force or _newer(out, deps):
-        cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include")] + files + \
-              ["-o", out, "-L", HERE, "-lcg_hip", "-Wl,-rpath,$ORIGIN/../conjugate-gradient_amd", "-lm"]
+        common = ["-std=c99", "-D_POSIX_C_SOURCE=200809L", "-O2", "-Wall", "-I", os.path.join(ROOT, "include")] + files
+        link = ["-L", HERE, "-lcg_hip", "-Wl,-rpath,$ORIGIN/../conjugate-gradient_amd", "-lm"]
+        cmd = ["gcc"] + common + ["-o", out] + link
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+        # one rank per GPU under mpirun, where an MPI is installed (MPICH under /opt/conda in this image)
+        # (gcc directly, not the mpicc wrapper: the wrapper's -L/opt/conda/lib would make the linker
+        # resolve the HIP runtime's libstdc++ against conda's older copy)
+        mpi = "/opt/conda"
+        if os.path.exists(os.path.join(mpi, "lib", "libmpi.so")):
+            cmd = ["gcc", "-DCG_USE_MPI", "-I", os.path.join(mpi, "include")] + common + ["-o", out + "_mpi"] + link + \
+                  [os.path.join(mpi, "lib", "libmpi.so"), "-Wl,--enable-new-dtags", "-Wl,-rpath," + os.path.join(mpi, "lib"),
+                   "-Wl,--allow-shlib-undefined"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
     return out
 
 

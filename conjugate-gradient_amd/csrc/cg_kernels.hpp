@@ -78,6 +78,17 @@ __device__ __forceinline__ double block_sum(double v, double *wave_slots)
     return s;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
+// vector-memory counter (s_waitcnt vmcnt(0)), which would retire every prefetched
+// global load at each row step and serialise the kernel on HBM latency; here the
+// global loads stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // XCD-aware placement: workgroups b, b+8, b+16, ... share an XCD (and its L2),
 // so hand each of those eight groups a contiguous run of tiles.  Bijective for
 // any tile count.  Affects speed only, never results.
@@ -109,22 +120,29 @@ struct StencilArgs {
     int remap;                        // 1 = XCD-aware tile order
 };
 
+// Streaming accesses carry the non-temporal hint (global_load/store ... nt): every
+// vector is touched once per kernel and is far larger than L2 + Infinity Cache, and
+// measured on MI355X the hint is worth 8-10 % of HBM bandwidth on mixed read/write
+// streams (5.3 -> 5.8 TB/s) and 15 % on pure reads (6.2 -> 7.2 TB/s).
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 template <int VEC> struct Pack;
 template <> struct Pack<1> {
     double v[1];
-    __device__ __forceinline__ void load(const double *p) { v[0] = *p; }
-    __device__ __forceinline__ void store(double *p) const { *p = v[0]; }
+    __device__ __forceinline__ void load(const double *p) { v[0] = __builtin_nontemporal_load(p); }
+    __device__ __forceinline__ void store(double *p) const { __builtin_nontemporal_store(v[0], p); }
 };
 template <> struct Pack<2> {
     double v[2];
     __device__ __forceinline__ void load(const double *p)
     {
-        const double2 t = *reinterpret_cast<const double2 *>(p);
+        const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
         v[0] = t.x; v[1] = t.y;
     }
     __device__ __forceinline__ void store(double *p) const
     {
-        *reinterpret_cast<double2 *>(p) = make_double2(v[0], v[1]);
+        v2d t; t.x = v[0]; t.y = v[1];
+        __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
     }
 };
 
@@ -142,18 +160,76 @@ __device__ __forceinline__ double five_point(double up, double left, double cent
     return acc;
 }
 
+// ---- buffer addressing -------------------------------------------------------
+// Every global access of the tiled kernel goes through a per-row buffer descriptor
+// (base = first element of the row, num_records = row bytes, or 0 when the row does
+// not exist / must not be written).  The hardware range check then does all the
+// masking -- columns past the grid, halo rows beyond the global boundary, rows that
+// belong to another tile, the strip-edge column that only two lanes fetch -- with
+// no branch: an out-of-range lane loads 0 and generates no memory traffic, an
+// out-of-range store is dropped.  The loop body stays one basic block, so the
+// compiler can keep PF rows of loads in flight behind counted s_waitcnt vmcnt(N).
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+constexpr int kRsrcFlags = 0x00020000;    // gfx9 raw buffer, 32-bit data format
+constexpr int kAuxNT = 2;                 // non-temporal (streaming) cache policy
+constexpr int kOOB = 0x7fffff00;          // byte offset beyond any row: lane is masked off
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double *row, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(row), 0, row != nullptr ? bytes : 0, kRsrcFlags);
+}
+
+template <int VEC> struct BufIO;
+template <> struct BufIO<1> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int off, double (&v)[1])
+    {
+        v[0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, kAuxNT));
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int off, const double (&v)[1])
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v[0]), r, off, 0, kAuxNT);
+    }
+};
+template <> struct BufIO<2> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int off, double (&v)[2])
+    {
+        const v2d t = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kAuxNT));
+        v[0] = t.x; v[1] = t.y;
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int off, const double (&v)[2])
+    {
+        v2d t; t.x = v[0]; t.y = v[1];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), r, off, 0, kAuxNT);
+    }
+};
+__device__ __forceinline__ double buf_load1(__amdgpu_buffer_rsrc_t r, int off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, int off, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, off, 0, kAuxNT);
+}
+
 // Raw operands of one grid row as a thread sees them: its VEC own columns plus,
 // for the first / last thread of the strip, the column just outside the strip.
-template <int VEC, bool FUSE_D>
+template <int VEC>
 struct RawRow {
-    Pack<VEC> d, g;
+    double d[VEC];                    // direction
+    double g[VEC];                    // gradient (MODE 1: operand of the d update; MODE 2: updated)
+    double u[VEC];                    // solution (MODE 2)
     double ed, eg;                    // edge column (threads 0 and kBlock-1 only)
 };
 
+// One workgroup walks down a column strip of kBlock*VEC columns with a rolling
+// three-row register window; left/right neighbours go through one LDS row.
+// PF rows of global loads are kept in flight ahead of the row being consumed.
+//
 // MODE 0: q = A d, partials of d.q                      (stencil entry points)
 // MODE 1: d' = beta*d - g, q = A d', partials of d'.q   (fused d-update)
 // MODE 2: q = A d recomputed, u += tau*d, g += tau*q, partials of g.g
-template <int VEC, int MODE, bool WRITE_Q>
+template <int VEC, int MODE, bool WRITE_Q, int PF>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 {
     constexpr bool FUSE_D = (MODE == 1);
@@ -172,91 +248,107 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     const long j = c0 + (long)tid * VEC;
     const long r0 = rt * a.tile_h;
     const long r1 = (r0 + a.tile_h < a.rows) ? r0 + a.tile_h : a.rows;
-    const bool col_ok = j < G;                       // VEC == 2 only with even G: all or nothing
+    const int rowbytes = (int)(G * 8);
     const bool left_edge = (tid == 0) && (c0 > 0);
     const bool right_edge = (tid == kBlock - 1) && (c0 + W < G);
-    const long je = left_edge ? c0 - 1 : c0 + W;
+
+    // Per-lane byte offsets inside a row; kOOB masks the lane off.
+    const int off_main = (j < G) ? (int)(j * 8) : kOOB;            // VEC == 2 only with even G: all or nothing
+    const int off_edge = left_edge ? (int)((c0 - 1) * 8) : (right_edge ? (int)((c0 + W) * 8) : kOOB);
+    // q is written on interior columns only (the reference never touches the rest):
+    // one vector store for lanes clear of the boundary, single-element stores for the
+    // two lanes that hold a boundary column.
+    int off_qv, off_q0 = kOOB, off_q1 = kOOB;
+    if (VEC == 2) {
+        off_qv = (j >= 1 && j + 1 <= G - 2) ? (int)(j * 8) : kOOB;
+        if (j == 0 && G >= 3) off_q1 = 8;                          // lane holds columns 0,1: store column 1
+        if (j == G - 2 && j >= 1) off_q0 = (int)(j * 8);           // lane holds columns G-2,G-1: store column G-2
+    } else {
+        off_qv = (j >= 1 && j <= G - 2) ? (int)(j * 8) : kOOB;
+    }
 
     double beta = 0.0, tau = 0.0;
     if (MODE == 1) beta = a.sc->beta;
     if (MODE == 2) tau = a.sc->tau;
 
-    // Row r of the block, r in [-1, rows]; -1 and rows are the halo rows.
+    // Row r of the block, r in [-1, rows]; -1 and rows are the halo rows (nullptr at
+    // the global boundary).  Everything here is wave-uniform scalar arithmetic.
     auto row_ptr = [&](const double *base, const double *top, const double *bot, long r) -> const double * {
-        if (r < 0) return top;
-        if (r >= a.rows) return bot;
-        return base + r * G;
+        return (r < 0) ? top : ((r >= a.rows) ? bot : base + r * G);
     };
-    auto load_row = [&](long r, RawRow<VEC, FUSE_D> &raw) {
+    auto load_row = [&](long r, RawRow<VEC> &raw) {
+        const bool live = r <= r1;                    // rows past the tile's lower halo are not needed
         const double *pd = row_ptr(a.d_in, a.d_top, a.d_bot, r);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) { raw.d.v[v] = 0.0; raw.g.v[v] = 0.0; }
-        raw.ed = 0.0; raw.eg = 0.0;
-        if (pd == nullptr) return;                    // beyond the global boundary
-        if (col_ok) raw.d.load(pd + j);
-        if (left_edge || right_edge) raw.ed = pd[je];
+        const __amdgpu_buffer_rsrc_t rd = row_rsrc(pd, live ? rowbytes : 0);
+        BufIO<VEC>::load(rd, off_main, raw.d);
+        raw.ed = buf_load1(rd, off_edge);
         if (FUSE_D) {
             const double *pg = row_ptr(a.g, a.g_top, a.g_bot, r);
-            if (col_ok) raw.g.load(pg + j);
-            if (left_edge || right_edge) raw.eg = pg[je];
+            const __amdgpu_buffer_rsrc_t rg = row_rsrc(pg, live ? rowbytes : 0);
+            BufIO<VEC>::load(rg, off_main, raw.g);
+            raw.eg = buf_load1(rg, off_edge);
+        } else {
+            raw.eg = 0.0;
+        }
+        if (MODE == 2) {
+            const bool own = (r >= r0) && (r < r1);
+            BufIO<VEC>::load(row_rsrc(a.u + r * G, own ? rowbytes : 0), off_main, raw.u);
+            BufIO<VEC>::load(row_rsrc(a.gw + r * G, own ? rowbytes : 0), off_main, raw.g);
         }
     };
 
-    double up[VEC], mid[VEC], midL = 0.0, midR = 0.0;
+    double up[VEC], mid[VEC], mid_u[VEC], mid_g[VEC], midL = 0.0, midR = 0.0;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { up[v] = 0.0; mid[v] = 0.0; }
+    for (int v = 0; v < VEC; ++v) { up[v] = 0.0; mid[v] = 0.0; mid_u[v] = 0.0; mid_g[v] = 0.0; }
     double acc = 0.0;
 
-    RawRow<VEC, FUSE_D> raw_next;
-    load_row(r0 - 1, raw_next);
+    RawRow<VEC> ring[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_row(r0 - 1 + p, ring[p]);
     int buf = 0;
-    for (long r = r0 - 1; r <= r1; ++r) {
-        RawRow<VEC, FUSE_D> raw = raw_next;
-        if (r + 1 <= r1) load_row(r + 1, raw_next);  // one row of loads in flight ahead of use
+    // Rows r0-1 .. r1 in groups of PF; a group may run past r1, those rows are fully
+    // masked (zero loads, dropped stores, zero contributions to the partial sum).
+    for (long rb = r0 - 1; rb <= r1; rb += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const long r = rb + p;
+            const RawRow<VEC> raw = ring[p];
+            load_row(r + PF, ring[p]);                // refill the slot: PF rows in flight
 
-        double cur[VEC], edge;
-        if (FUSE_D) {
+            double cur[VEC], edge;
+            if (FUSE_D) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) cur[v] = beta * raw.d.v[v] - raw.g.v[v];
-            edge = beta * raw.ed - raw.eg;
-            if (col_ok) {
-                // Owned rows go to d_out; a neighbour's boundary row (known here only
-                // as a halo) is kept up to date locally, so that only g has to travel.
-                double *dst = nullptr;
-                if (r >= r0 && r < r1) dst = a.d_out + r * G + j;
-                else if (r < 0) dst = a.d_top_out ? a.d_top_out + j : nullptr;
-                else if (r >= a.rows) dst = a.d_bot_out ? a.d_bot_out + j : nullptr;
-                if (dst != nullptr) {
-                    Pack<VEC> o;
+                for (int v = 0; v < VEC; ++v) cur[v] = beta * raw.d[v] - raw.g[v];
+                edge = beta * raw.ed - raw.eg;
+                // Owned rows go to d_out; a neighbour's boundary row (known here only as a
+                // halo) is kept up to date locally, so that only g has to travel.
+                const double *dst = (r >= r0 && r < r1) ? a.d_out + r * G
+                                  : ((r < 0) ? a.d_top_out : ((r >= a.rows && r <= r1) ? a.d_bot_out : nullptr));
+                BufIO<VEC>::store(row_rsrc(dst, rowbytes), off_main, cur);
+            } else {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o.v[v] = cur[v];
-                    o.store(dst);
-                }
+                for (int v = 0; v < VEC; ++v) cur[v] = raw.d[v];
+                edge = raw.ed;
             }
-        } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) cur[v] = raw.d.v[v];
-            edge = raw.ed;
-        }
 
-        // Left/right neighbours travel through one LDS row (double-buffered, so a
-        // single barrier per row orders both the writes before the reads and the
-        // reads before the buffer's next reuse two rows later).
-        double *L = row_lds[buf];
+            // Left/right neighbours travel through one LDS row (double-buffered, so a
+            // single barrier per row orders both the writes before the reads and the
+            // reads before the buffer's next reuse two rows later).
+            double *L = row_lds[buf];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) L[1 + tid * VEC + v] = cur[v];
-        if (tid == 0) L[0] = edge;
-        if (tid == kBlock - 1) L[W + 1] = edge;
-        __syncthreads();
-        const double curL = L[tid * VEC];
-        const double curR = L[tid * VEC + VEC + 1];
-        buf ^= 1;
+            for (int v = 0; v < VEC; ++v) L[1 + tid * VEC + v] = cur[v];
+            if (tid == 0) L[0] = edge;
+            if (tid == kBlock - 1) L[W + 1] = edge;
+            lds_barrier();
+            const double curL = L[tid * VEC];
+            const double curR = L[tid * VEC + VEC + 1];
+            buf ^= 1;
 
-        // Rows r-2 (up), r-1 (mid) and r (cur) are now in registers: emit row r-1.
-        const long m = r - 1;
-        if (m >= r0) {
+            // Rows r-2 (up), r-1 (mid) and r (cur) are now in registers: emit row r-1.
+            const long m = r - 1;
             const long gi = a.row0 + m;
-            const bool row_in = (gi >= 1) && (gi <= G - 2);
+            const bool row_own = (m >= r0) && (m < r1);
+            const bool row_in = row_own && (gi >= 1) && (gi <= G - 2);
             double qv[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -266,43 +358,31 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 qv[v] = in ? five_point(up[v], left, mid[v], right, cur[v]) : 0.0;
             }
             if (MODE == 2) {
-                if (col_ok) {
-                    Pack<VEC> pu, pg;
-                    pu.load(a.u + m * G + j);
-                    pg.load(a.gw + m * G + j);
+                double pu[VEC], pg[VEC];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        pu.v[v] = pu.v[v] + tau * mid[v];
-                        pg.v[v] = pg.v[v] + tau * qv[v];
-                        acc += pg.v[v] * pg.v[v];
-                    }
-                    pu.store(a.u + m * G + j);
-                    pg.store(a.gw + m * G + j);
+                for (int v = 0; v < VEC; ++v) {
+                    pu[v] = mid_u[v] + tau * mid[v];
+                    pg[v] = mid_g[v] + tau * qv[v];
+                    acc += pg[v] * pg[v];             // masked rows/lanes hold g = 0
                 }
+                BufIO<VEC>::store(row_rsrc(a.u + m * G, row_own ? rowbytes : 0), off_main, pu);
+                BufIO<VEC>::store(row_rsrc(a.gw + m * G, row_own ? rowbytes : 0), off_main, pg);
             } else {
-                if (col_ok) {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc += mid[v] * qv[v];
-                    if (WRITE_Q && row_in) {
-                        // Boundary columns of an interior row are not written by the
-                        // reference either; q there keeps its initial zero.
-                        if (VEC == 2 && j >= 1 && j + 1 <= G - 2) {
-                            Pack<VEC> o;
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) o.v[v] = qv[v];
-                            o.store(a.q + m * G + j);
-                        } else {
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v)
-                                if (j + v >= 1 && j + v <= G - 2) a.q[m * G + j + v] = qv[v];
-                        }
+                for (int v = 0; v < VEC; ++v) acc += mid[v] * qv[v];   // q = 0 off the interior
+                if (WRITE_Q) {
+                    const __amdgpu_buffer_rsrc_t rq = row_rsrc(a.q + m * G, row_in ? rowbytes : 0);
+                    BufIO<VEC>::store(rq, off_qv, qv);
+                    if (VEC == 2) {
+                        buf_store1(rq, off_q0, qv[0]);
+                        buf_store1(rq, off_q1, qv[VEC - 1]);
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { up[v] = mid[v]; mid[v] = cur[v]; }
-        midL = curL; midR = curR;
+            for (int v = 0; v < VEC; ++v) { up[v] = mid[v]; mid[v] = cur[v]; mid_u[v] = raw.u[v]; mid_g[v] = raw.g[v]; }
+            midL = curL; midR = curR;
+        }
     }
 
     const double s = block_sum(acc, wave_slots);

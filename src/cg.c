@@ -1,0 +1,215 @@
+/*
+ * C driver of the MI355X conjugate-gradient solver: the reference's command line
+ * and output (cg.c:8-153), with the numerical work done on the GPU.
+ *
+ *   cg <n> [iters] [rtol]
+ *
+ *   n      grid has (n+1) x (n+1) points, as in the reference (cg.c:20)
+ *   iters  iteration count, default MAX_ITERS = 200 (utils.h:1, a compile-time
+ *          constant in the reference)
+ *   rtol   optional stop rule sqrt(q1/q_init) <= rtol (the reference has none)
+ *
+ * Environment:
+ *   CG_PATH=solve   (default) whole loop on the device: cg_solve, device-resident
+ *                   scalars, fused kernels, hipGraph
+ *   CG_PATH=calls   the reference's own loop structure (cg.c:53-130), one library
+ *                   call per step through the utils.h entry points
+ *   CG_STRICT=1     dot products in the reference's exact summation order
+ *                   (bit-identical results, slow)
+ *   CG_SCHEDULE=classic|fused|fused_noq   kernel schedule of the solve path
+ *   CG_DUMP=prefix  write the final u as raw doubles to <prefix>.u.f64 (1 rank)
+ *
+ * Output on rank 0: the reference's two lines (cg.c:139-140) followed by one
+ * machine-readable line with full-precision q1, rates and achieved bandwidth.
+ *
+ * More than one rank: build with -DCG_USE_MPI and start one rank per GPU with
+ * mpirun; rank r owns rows [r*(n+1)/P, (r+1)*(n+1)/P).  Any P that divides n+1
+ * is accepted (the reference needs a perfect square, cg.c:15).
+ */
+#ifdef CG_USE_MPI
+#include <mpi.h>
+#endif
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "utils.h"
+#include "cg_hip.h"
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void die(const char *what)
+{
+    fprintf(stderr, "[ERROR] %s: %s\n", what, cg_last_error());
+    exit(1);
+}
+#define CK(call, what) do { if ((call) != CG_OK) die(what); } while (0)
+
+static void barrier(void)
+{
+#ifdef CG_USE_MPI
+    MPI_Barrier(MPI_COMM_WORLD);
+#endif
+}
+
+int main(int argc, char **argv)
+{
+    int rank = 0, numprocs = 1;
+#ifdef CG_USE_MPI
+    MPI_Init(&argc, &argv);
+    MPI_Comm_size(MPI_COMM_WORLD, &numprocs);
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+#endif
+    if (argc < 2) {
+        if (rank == 0) fprintf(stderr, "usage: %s <n> [iters] [rtol]\n", argv[0]);
+        return 1;
+    }
+    const int n = atoi(argv[1]);
+    const long iters = argc > 2 ? atol(argv[2]) : MAX_ITERS;
+    const double rtol = argc > 3 ? atof(argv[3]) : 0.0;
+    if (n < 2 || iters < 0 || rtol < 0) {
+        if (rank == 0) printf("[ERROR] need n >= 2, iters >= 0, rtol >= 0.\n");
+        return 1;
+    }
+    const long G = (long)n + 1;
+    if (G % numprocs != 0) {                                   /* cg.c:23-26, for row blocks */
+        if (rank == 0) printf("[ERROR] Number of points '%d+1' not divisible by number of processors '%d'.\n", n, numprocs);
+        return 1;
+    }
+    const long rows = G / numprocs, row0 = rank * rows, count = rows * G;
+    const char *path = getenv("CG_PATH");
+    const char *strict_e = getenv("CG_STRICT");
+    const int strict = strict_e && *strict_e && *strict_e != '0';
+    const int use_calls = path && strcmp(path, "calls") == 0;
+
+    double q1 = 0.0, q_init = 0.0, runtime = 0.0;
+    long done_iters = 0;
+    int bytes_per_point = 88;
+    double *u_dev = NULL;
+    int device = 0;
+
+    if (use_calls) {
+        /* ---- the reference's loop, one call per step (cg.c:30-130) ---- */
+        bytes_per_point = 112;                                         /* six separate passes, as in the reference */
+        MPI_Settings *settings = init_mpi_settings(numprocs, (int)G);
+        device = settings->device;
+        settings->strict_dot = strict;
+        int my_stencil[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};          /* cg.c:33 */
+        stencil_struct *stencil = (stencil_struct *)malloc(sizeof(stencil_struct));
+        stencil->size = 3;
+        stencil->extent = stencil->size / 2;
+        stencil->stencil = (int *)malloc(sizeof(my_stencil));
+        memcpy(stencil->stencil, my_stencil, sizeof(my_stencil));
+
+        d_struct *ld = init_locald(n, (int)G, rank, settings);         /* cg.c:41 */
+        double *locald = ld->locald;
+        double *localg = init_localg((int)G, locald);                  /* cg.c:43 */
+        double *localu = NULL, *localq = NULL;
+        CK(cg_malloc(device, count, &localu), "cg_malloc(u)");         /* cg.c:44 */
+        CK(cg_malloc(device, count, &localq), "cg_malloc(q)");         /* cg.c:45 */
+
+        double q0, tau, beta;
+        barrier();                                                     /* cg.c:50 */
+        const double t0 = now_s();
+        dot((int)G, (int)G, localg, localg, settings->cartcomm, &q0);  /* cg.c:55 */
+        q_init = q1 = q0;
+        const double stop = rtol * rtol * q0;
+        for (long it = 0; it < iters; ++it) {
+            if (numprocs == 1) apply_stencil_serial(n, stencil, locald, localq);                       /* cg.c:58 */
+            else apply_stencil_parallel((int)G, stencil, ld, localq, rank, settings);                  /* cg.c:97 */
+            dot((int)G, (int)G, locald, localq, settings->cartcomm, &tau);                             /* cg.c:61 */
+            tau = q0 / tau;                                                                            /* cg.c:62 */
+            CK(cg_axpy(device, count, tau, locald, localu), "cg_axpy(u)");                             /* cg.c:63-69 */
+            CK(cg_axpy(device, count, tau, localq, localg), "cg_axpy(g)");                             /* cg.c:70-76 */
+            dot((int)G, (int)G, localg, localg, settings->cartcomm, &q1);                              /* cg.c:79 */
+            beta = q1 / q0;                                                                            /* cg.c:80 */
+            CK(cg_xpay(device, count, beta, locald, localg), "cg_xpay(d)");                            /* cg.c:81-87 */
+            q0 = q1;                                                                                   /* cg.c:89 */
+            done_iters = it + 1;
+            if (rtol > 0 && q1 <= stop) break;
+        }
+        barrier();                                                     /* cg.c:131 */
+        runtime = now_s() - t0;
+        u_dev = localu;
+        const char *dump = getenv("CG_DUMP");
+        if (dump && *dump && numprocs == 1) {
+            double *h = (double *)malloc((size_t)count * sizeof(double));
+            char fn[4096];
+            snprintf(fn, sizeof fn, "%s.u.f64", dump);
+            CK(cg_copy_to_host(device, h, u_dev, count), "cg_copy_to_host");
+            FILE *f = fopen(fn, "wb");
+            if (f) { fwrite(h, sizeof(double), (size_t)count, f); fclose(f); }
+            free(h);
+        }
+        cg_free(device, localu); cg_free(device, localg); cg_free(device, localq);
+        free_struct_elems(stencil, ld, settings);
+        free(ld); free(stencil); free(settings);
+    } else {
+        /* ---- whole loop on the device ---- */
+        int ndev = 0;
+        CK(cg_device_count(&ndev), "cg_device_count");
+        if (ndev < 1) { if (rank == 0) printf("[ERROR] no GPU visible; this build has no CPU path.\n"); return 1; }
+        device = rank % ndev;
+        cg_ctx *ctx = NULL;
+        CK(cg_create(&ctx, device, n, row0, rows, rank, numprocs), "cg_create");
+        const char *se = getenv("CG_SCHEDULE");
+        int sched = strict ? CG_SCHED_CLASSIC : CG_SCHED_FUSED_NOQ;
+        if (se && strcmp(se, "classic") == 0) sched = CG_SCHED_CLASSIC;
+        else if (se && strcmp(se, "fused") == 0) sched = CG_SCHED_FUSED;
+        else if (se && strcmp(se, "fused_noq") == 0) sched = CG_SCHED_FUSED_NOQ;
+        CK(cg_set_option(ctx, CG_OPT_REDUCE, strict ? CG_REDUCE_STRICT : CG_REDUCE_FAST), "cg_set_option(reduce)");
+        CK(cg_set_option(ctx, CG_OPT_SCHEDULE, sched), "cg_set_option(schedule)");
+        bytes_per_point = sched == CG_SCHED_CLASSIC ? 88 : (sched == CG_SCHED_FUSED ? 80 : 64);
+#ifdef CG_USE_MPI
+        if (numprocs > 1) {
+            char id[128];
+            if (rank == 0) CK(cg_comm_unique_id(id), "cg_comm_unique_id");
+            MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+            CK(cg_comm_init(ctx, id), "cg_comm_init");
+        }
+#endif
+        CK(cg_init_problem(ctx), "cg_init_problem");
+        cg_result res;
+        barrier();
+        const double t0 = now_s();
+        CK(cg_solve(ctx, iters, rtol, &res), "cg_solve");
+        barrier();
+        runtime = now_s() - t0;
+        q1 = res.q1; q_init = res.q_init; done_iters = res.iters;
+        const char *dump = getenv("CG_DUMP");
+        if (dump && *dump && numprocs == 1) {
+            double *h = (double *)malloc((size_t)count * sizeof(double));
+            char fn[4096];
+            snprintf(fn, sizeof fn, "%s.u.f64", dump);
+            CK(cg_copy_out(ctx, CG_VEC_U, h, count), "cg_copy_out");
+            FILE *f = fopen(fn, "wb");
+            if (f) { fwrite(h, sizeof(double), (size_t)count, f); fclose(f); }
+            free(h);
+        }
+        cg_destroy(ctx);
+    }
+
+    double max_runtime = runtime;
+#ifdef CG_USE_MPI
+    MPI_Reduce(&runtime, &max_runtime, 1, MPI_DOUBLE, MPI_MAX, 0, MPI_COMM_WORLD);    /* cg.c:134 */
+#endif
+    if (rank == 0) {
+        printf("[INFO] norm_g^2 = %.16lf\n", q1);                                       /* cg.c:139 */
+        printf("%.16lf\n", max_runtime);                                                /* cg.c:140 */
+        const double its = max_runtime > 0 ? (double)done_iters / max_runtime : 0.0;
+        printf("[CG] q1 = %.17e (%a) q_init = %.17e iters=%ld np=%d path=%s order=%s it/s=%.3f hbm_GBs_per_gpu=%.1f\n",
+               q1, q1, q_init, done_iters, numprocs, use_calls ? "calls" : "solve", strict ? "strict" : "fast", its,
+               (double)bytes_per_point * (double)count * its / 1e9);
+    }
+#ifdef CG_USE_MPI
+    MPI_Finalize();
+#endif
+    return 0;
+}

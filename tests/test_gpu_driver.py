@@ -1,0 +1,94 @@
+"""The C driver (src/cg, the reference's command line) and the utils.h entry points on a real GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits, golden_arrays
+
+pytestmark = pytest.mark.gpu
+
+CG = os.path.join(ROOT, "src", "cg")
+CG_MPI = os.path.join(ROOT, "src", "cg_mpi")
+MPIRUN = "/opt/conda/bin/mpirun"
+LINE = re.compile(r"\[CG\] q1 = (\S+) \((\S+)\) q_init = (\S+) iters=(\d+) np=(\d+) path=(\w+) order=(\w+)")
+
+
+def run(args, env=None, mpi=0, timeout=240):
+    cmd = [CG] + args if not mpi else [MPIRUN, "-np", str(mpi), CG_MPI] + args
+    p = subprocess.run(cmd, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout + p.stderr
+    m = LINE.search(p.stdout)
+    assert m, p.stdout
+    return p.stdout.splitlines(), m
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+def test_reference_output_lines_and_strict_parity(golden):
+    rec = golden[(255, 200, 1, 0.0)]
+    lines, m = run(["255"], env={"CG_STRICT": "1"})
+    # the reference prints exactly this for ./cg 255 (cg.c:139): the same text, digit for digit
+    assert lines[0] == "[INFO] norm_g^2 = %.16f" % float.fromhex(rec["q1_hex"])
+    assert re.fullmatch(r"\d+\.\d{16}", lines[1])
+    assert m.group(2) == rec["q1_hex"] and int(m.group(4)) == 200 and m.group(7) == "strict"
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+@pytest.mark.parametrize("path", ["solve", "calls"])
+def test_driver_paths_fast_order(golden, path):
+    rec = golden[(255, 200, 1, 0.0)]
+    lines, m = run(["255"], env={"CG_PATH": path})
+    q1_ref = float.fromhex(rec["q1_hex"])
+    assert abs(float(m.group(1)) - q1_ref) <= 5e-8 * q1_ref
+    assert lines[0].startswith("[INFO] norm_g^2 = 0.00000000074333")
+    assert m.group(6) == path
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+def test_calls_path_strict_is_bit_identical_and_dumps_u(golden, tmp_path):
+    rec = golden[(63, 50, 1, 0.0)]
+    prefix = str(tmp_path / "dump")
+    _, m = run(["63", "50"], env={"CG_PATH": "calls", "CG_STRICT": "1", "CG_DUMP": prefix})
+    assert m.group(2) == rec["q1_hex"]
+    u = np.fromfile(prefix + ".u.f64", dtype="<f8").reshape(64, 64)
+    assert np.array_equal(bits(u), bits(golden_arrays(rec["arrays"], 63)["u"]))
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+def test_runtime_iteration_count_and_stop_rule(golden):
+    rec = golden[(1023, 1000, 1, 0.0)]
+    _, m = run(["1023", "1000"])
+    q1_ref = float.fromhex(rec["q1_hex"])
+    assert int(m.group(4)) == 1000 and abs(float(m.group(1)) - q1_ref) <= 5e-7 * q1_ref
+    rec = golden[(255, 10000, 1, 1e-8)]
+    _, m = run(["255", "10000", "1e-8"], env={"CG_STRICT": "1"})
+    assert int(m.group(4)) == rec["iters"] and m.group(2) == rec["q1_hex"]
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+def test_bad_arguments_are_rejected():
+    p = subprocess.run([CG, "1"], capture_output=True, text=True)
+    assert p.returncode == 1 and "[ERROR]" in p.stdout
+    p = subprocess.run([CG], capture_output=True, text=True)
+    assert p.returncode == 1
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_row_blocks_over_mpi_ranks_strict_is_bit_identical(golden, ranks):
+    # Several ranks sharing the one GPU of the test box: row blocks, halo rows through
+    # exchange_boundaries, the accumulator of each dot product handed from rank to rank.
+    # The result must equal the reference's single-rank numbers bit for bit.
+    rec = golden[(255, 200, 1, 0.0)]
+    _, m = run(["255"], env={"CG_PATH": "calls", "CG_STRICT": "1"}, mpi=ranks)
+    assert m.group(2) == rec["q1_hex"] and int(m.group(5)) == ranks
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+def test_row_blocks_over_mpi_ranks_fast_order(golden):
+    rec = golden[(255, 200, 1, 0.0)]
+    _, m = run(["255"], env={"CG_PATH": "calls"}, mpi=2)
+    q1_ref = float.fromhex(rec["q1_hex"])
+    assert abs(float(m.group(1)) - q1_ref) <= 5e-8 * q1_ref

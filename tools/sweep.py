@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Kernel-level sweep of launch geometry on the 16384^2 grid (HIP-event timed, GB/s of algorithmic bytes)."""
+import importlib, itertools, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+cg = importlib.import_module("conjugate-gradient_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16383
+tiles = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 128, 256, 512, 1024]
+scheds = {"noq": cg.SCHED_FUSED_NOQ, "classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED}
+which_s = sys.argv[3].split(",") if len(sys.argv) > 3 else ["noq"]
+pfs = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [4]
+s = cg.CGSolver(n)
+for name in which_s:
+    sched = scheds[name]
+    for pf in pfs:
+        for th in tiles:
+            s.configure(schedule=sched, tile_h=th, xcd_remap=1, prefetch=pf).init_problem()
+            line = f"pf={pf} {name:8s} tile_h={th:5d}"
+            tot = 0.0
+            for which in (0, 1):
+                ms, nb = s.time_kernel(which, reps=10)
+                tot += ms
+                line += f"  k{which}: {ms:7.3f} ms {nb/ms/1e6:7.0f} GB/s"
+            print(line + f"  sum {tot:.3f}", flush=True)
