@@ -1,13 +1,20 @@
-// RCCL plumbing of the row-block multi-GPU solve: one process per GPU, rank r
+// Communication of the row-block multi-GPU solve: one process per GPU, rank r
 // owns rows [r*G/P, (r+1)*G/P), neighbours are r-1 (above) and r+1 (below).
 //
 // Replaces, for the row direction, init_mpi_settings (utils.c:383-420),
 // exchange_boundaries (utils.c:231-248: Isend/Irecv of the first and last row)
 // and the MPI_Allreduce of one double in dot (utils.c:380).
 //
-// librccl is opened with dlopen on first use, so a single-GPU process never
-// loads it and the library has no link-time dependency on it.  Inside a
-// PyTorch process the already loaded librccl.so.1 is the one that is found.
+// Two transports behind one interface:
+//   RcclComm  RCCL over xGMI, stream-ordered, no host involvement (the fast path).
+//             librccl is opened with dlopen on first use, so a single-GPU process
+//             never loads it and the library has no link-time dependency on it;
+//             inside a PyTorch process the already loaded librccl.so.1 is found.
+//   HostComm  device rows / scalars are staged through pinned host memory and
+//             handed to two caller-supplied functions (MPI, torch.distributed
+//             with gloo, ...).  Synchronous and slow; it exists so that every
+//             multi-rank code path of the solver can be exercised by several
+//             processes sharing ONE GPU, and as a fallback where RCCL is absent.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -16,7 +23,41 @@
 #include <cstdio>
 #include <cstring>
 
+#include "../../include/cg_hip.h"
+
 namespace cg {
+
+class Comm {
+public:
+    virtual ~Comm()
+    {
+        if (gather_) (void)hipFree(gather_);
+    }
+    const char *error() const { return err_; }
+    // Device buffer of nranks doubles; slot `rank` is this rank's contribution.
+    double *gather_buf() { return gather_; }
+    // In-place all-gather of one double per rank, ordered after prior work on s.
+    virtual int allgather_scalar(hipStream_t s) = 0;
+    // Send the block's first row up and its last row down; receive the neighbours'
+    // boundary rows into top_dst / bot_dst.  Ordered after prior work on s.
+    virtual int exchange_rows(hipStream_t s, const double *base, long rows, long G, double *top_dst, double *bot_dst) = 0;
+    // True if the calls above only enqueue stream work (hipGraph-capturable).
+    virtual bool stream_ordered() const = 0;
+
+protected:
+    bool alloc_gather(int nranks)
+    {
+        return hipMalloc(&gather_, (size_t)nranks * sizeof(double)) == hipSuccess &&
+               hipMemset(gather_, 0, (size_t)nranks * sizeof(double)) == hipSuccess &&
+               hipStreamSynchronize(nullptr) == hipSuccess;
+    }
+    double *gather_ = nullptr;
+    int rank_ = 0, nranks_ = 1;
+    bool has_top_ = false, has_bot_ = false;
+    char err_[256] = "";
+};
+
+// ------------------------------------------------------------------- RCCL ----
 
 struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -68,7 +109,7 @@ struct RcclApi {
     }
 };
 
-class Comm {
+class RcclComm : public Comm {
 public:
     static int unique_id(void *id128, char *msg, size_t n)
     {
@@ -83,11 +124,11 @@ public:
     }
 
     // Collective over all ranks; the current HIP device must be this rank's GPU.
-    static Comm *create(const void *id128, int rank, int nranks, bool has_top, bool has_bot, char *msg, size_t n)
+    static RcclComm *create(const void *id128, int rank, int nranks, bool has_top, bool has_bot, char *msg, size_t n)
     {
         RcclApi *api = RcclApi::get(msg, n);
         if (!api) return nullptr;
-        Comm *c = new Comm;
+        RcclComm *c = new RcclComm;
         c->api_ = api; c->rank_ = rank; c->nranks_ = nranks; c->has_top_ = has_top; c->has_bot_ = has_bot;
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
@@ -98,8 +139,7 @@ public:
             delete c;
             return nullptr;
         }
-        if (hipMalloc(&c->gather_, (size_t)nranks * sizeof(double)) != hipSuccess ||
-            hipMemset(c->gather_, 0, (size_t)nranks * sizeof(double)) != hipSuccess) {
+        if (!c->alloc_gather(nranks)) {
             snprintf(msg, n, "hipMalloc of the all-gather buffer failed");
             delete c;
             return nullptr;
@@ -107,25 +147,20 @@ public:
         return c;
     }
 
-    ~Comm()
+    ~RcclComm() override
     {
         if (comm_) (void)api_->CommDestroy(comm_);
-        if (gather_) (void)hipFree(gather_);
     }
 
-    const char *error() const { return err_; }
-    double *gather_buf() { return gather_; }
+    bool stream_ordered() const override { return true; }
 
-    // In-place all-gather of one double per rank: slot `rank` of gather_buf()
-    // goes out, all slots come back.  Stream-ordered (graph-capturable).
-    int allgather_scalar(hipStream_t s)
+    int allgather_scalar(hipStream_t s) override
     {
         return check(api_->AllGather(gather_ + rank_, gather_, 1, ncclDouble, comm_, s), "ncclAllGather");
     }
 
-    // Send the block's first row up and last row down; receive the neighbours'
-    // boundary rows into top_dst / bot_dst.  One grouped RCCL launch.
-    int exchange_rows(hipStream_t s, const double *base, long rows, long G, double *top_dst, double *bot_dst)
+    // One grouped RCCL launch for the (up to) two sends and two receives.
+    int exchange_rows(hipStream_t s, const double *base, long rows, long G, double *top_dst, double *bot_dst) override
     {
         if (!has_top_ && !has_bot_) return 0;
         int rc = check(api_->GroupStart(), "ncclGroupStart");
@@ -150,10 +185,76 @@ private:
     }
     RcclApi *api_ = nullptr;
     ncclComm_t comm_ = nullptr;
-    double *gather_ = nullptr;
-    int rank_ = 0, nranks_ = 1;
-    bool has_top_ = false, has_bot_ = false;
-    char err_[256] = "";
+};
+
+// ------------------------------------------------------------- host-staged ---
+
+class HostComm : public Comm {
+public:
+    static HostComm *create(cg_exchange_fn ex, cg_allgather_fn ag, void *user, int rank, int nranks, long G,
+                            bool has_top, bool has_bot, char *msg, size_t n)
+    {
+        HostComm *c = new HostComm;
+        c->ex_ = ex; c->ag_ = ag; c->user_ = user;
+        c->rank_ = rank; c->nranks_ = nranks; c->has_top_ = has_top; c->has_bot_ = has_bot; c->G_ = G;
+        const size_t row = (size_t)G * sizeof(double);
+        bool ok = c->alloc_gather(nranks);
+        for (int i = 0; i < 4 && ok; ++i) ok = hipHostMalloc(reinterpret_cast<void **>(&c->rowbuf_[i]), row, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->hgather_), (size_t)nranks * sizeof(double), hipHostMallocDefault) == hipSuccess;
+        if (!ok) { snprintf(msg, n, "allocation of the host staging buffers failed"); delete c; return nullptr; }
+        return c;
+    }
+
+    ~HostComm() override
+    {
+        for (double *p : rowbuf_) if (p) (void)hipHostFree(p);
+        if (hgather_) (void)hipHostFree(hgather_);
+    }
+
+    bool stream_ordered() const override { return false; }
+
+    int allgather_scalar(hipStream_t s) override
+    {
+        if (hip(hipMemcpyAsync(hgather_ + rank_, gather_ + rank_, sizeof(double), hipMemcpyDeviceToHost, s), "D2H scalar")) return -1;
+        if (hip(hipStreamSynchronize(s), "sync")) return -1;
+        const double mine = hgather_[rank_];
+        if (ag_(user_, mine, hgather_) != 0) { snprintf(err_, sizeof err_, "host all-gather callback failed"); return -1; }
+        if (hip(hipMemcpyAsync(gather_, hgather_, (size_t)nranks_ * sizeof(double), hipMemcpyHostToDevice, s), "H2D scalars")) return -1;
+        return hip(hipStreamSynchronize(s), "sync");
+    }
+
+    int exchange_rows(hipStream_t s, const double *base, long rows, long G, double *top_dst, double *bot_dst) override
+    {
+        if (!has_top_ && !has_bot_) return 0;
+        if (G != G_) { snprintf(err_, sizeof err_, "row length changed"); return -1; }
+        const size_t row = (size_t)G * sizeof(double);
+        double *send_up = rowbuf_[0], *send_down = rowbuf_[1], *recv_top = rowbuf_[2], *recv_bot = rowbuf_[3];
+        if (has_top_ && hip(hipMemcpyAsync(send_up, base, row, hipMemcpyDeviceToHost, s), "D2H first row")) return -1;
+        if (has_bot_ && hip(hipMemcpyAsync(send_down, base + (rows - 1) * G, row, hipMemcpyDeviceToHost, s), "D2H last row")) return -1;
+        if (hip(hipStreamSynchronize(s), "sync")) return -1;
+        if (ex_(user_, has_top_ ? send_up : nullptr, has_bot_ ? send_down : nullptr, has_top_ ? recv_top : nullptr,
+                has_bot_ ? recv_bot : nullptr, G) != 0) {
+            snprintf(err_, sizeof err_, "host halo-exchange callback failed");
+            return -1;
+        }
+        if (has_top_ && hip(hipMemcpyAsync(top_dst, recv_top, row, hipMemcpyHostToDevice, s), "H2D top row")) return -1;
+        if (has_bot_ && hip(hipMemcpyAsync(bot_dst, recv_bot, row, hipMemcpyHostToDevice, s), "H2D bottom row")) return -1;
+        return hip(hipStreamSynchronize(s), "sync");
+    }
+
+private:
+    int hip(hipError_t e, const char *what)
+    {
+        if (e == hipSuccess) return 0;
+        snprintf(err_, sizeof err_, "%s: %s", what, hipGetErrorString(e));
+        return -1;
+    }
+    cg_exchange_fn ex_ = nullptr;
+    cg_allgather_fn ag_ = nullptr;
+    void *user_ = nullptr;
+    long G_ = 0;
+    double *rowbuf_[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *hgather_ = nullptr;
 };
 
 } // namespace cg

@@ -118,6 +118,11 @@ struct StencilArgs {
     int nstrips;                      // column strips per row of tiles
     int tile_h;                       // rows per tile
     int remap;                        // 1 = XCD-aware tile order
+    // A launch may cover a subset of the block's row tiles (multi-GPU overlap: the
+    // tiles that need no halo row run while the halo rows are still in flight).
+    int rt_first;                     // first row tile of this launch
+    int rt_total;                     // row tiles in the whole block
+    int edge_pair;                    // 1 = this launch covers row tiles 0 and rt_total-1 only
 };
 
 // Streaming accesses carry the non-temporal hint (global_load/store ... nt): every
@@ -241,8 +246,10 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 
     const int tid = threadIdx.x;
     const long ntiles = (long)gridDim.x;
-    const long tile = a.remap ? xcd_remap(blockIdx.x, ntiles) : (long)blockIdx.x;
-    const long strip = tile % a.nstrips, rt = tile / a.nstrips;
+    const long lt = a.remap ? xcd_remap(blockIdx.x, ntiles) : (long)blockIdx.x;
+    const long strip = lt % a.nstrips, lrt = lt / a.nstrips;
+    const long rt = a.edge_pair ? (lrt == 0 ? 0 : a.rt_total - 1) : a.rt_first + lrt;
+    const long tile = rt * a.nstrips + strip;         // index in the whole block: fixes the partial's slot
     const long G = a.G;
     const long c0 = strip * W;
     const long j = c0 + (long)tid * VEC;

@@ -140,10 +140,14 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
     return t;
 }
 
+// Launches the row tiles the arguments select: all of them (rt_first = 0), a
+// contiguous run starting at rt_first, or the first and last one (edge_pair).
 template <int MODE, bool WRITE_Q>
-void launch_stencil(const TileGeom &t, const StencilArgs &a, hipStream_t s)
+void launch_stencil(const TileGeom &t, const StencilArgs &a, hipStream_t s, long row_tiles = -1)
 {
-    const dim3 grid((unsigned)t.ntiles), block(kBlock);
+    const long nrt = row_tiles >= 0 ? row_tiles : t.ntiles / t.nstrips;
+    if (nrt <= 0) return;
+    const dim3 grid((unsigned)(nrt * t.nstrips)), block(kBlock);
 #define CG_LAUNCH(V, P) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P>), grid, block, 0, s, a)
     if (t.vec == 2) {
         switch (t.pf) {
@@ -177,6 +181,7 @@ struct cg_ctx {
     int remap = 1;
     long flat_blocks_opt = 0;
     int prefetch = 4;
+    bool graph_explicit = false;          // the caller set CG_OPT_GRAPH_ITERS
 
     // device state
     hipStream_t stream = nullptr;
@@ -197,6 +202,8 @@ struct cg_ctx {
     double *halo_d[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [buffer][top/bot]
     double *halo_g[2] = {nullptr, nullptr};
     cg::Comm *comm = nullptr;
+    hipStream_t comm_stream = nullptr;    // halo exchange runs here, beside the interior stencil
+    hipEvent_t ev_fork = nullptr, ev_halo = nullptr;
 
     // captured iteration body
     hipGraphExec_t graph = nullptr;
@@ -271,6 +278,7 @@ StencilArgs base_args(cg_ctx *c, const TileGeom &t)
     a.sc = c->sc;
     a.G = c->G; a.rows = c->rows; a.row0 = c->row0;
     a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = c->remap;
+    a.rt_first = 0; a.rt_total = (int)(t.ntiles / t.nstrips); a.edge_pair = 0;
     return a;
 }
 
@@ -288,12 +296,31 @@ int enqueue_iteration(cg_ctx *c, bool first)
     a.partials = p_dq;
     a.q = c->q;
     const bool fuse = (sched != CG_SCHED_CLASSIC) && !first;
+    bool split = false;                   // interior tiles run beside the halo exchange
     if (c->nranks > 1) {
         // Row halos: the fused kernel needs the neighbours' boundary rows of g (d's
         // halo rows are kept current locally); the plain kernel needs those of d.
-        if (fuse) CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
-        else if (!first || sched == CG_SCHED_CLASSIC)
-            CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->d[c->dcur], c->rows, c->G, c->halo_d[c->dcur][0], c->halo_d[c->dcur][1])));
+        if (fuse) {
+            // beta (from the all-gather that has just completed on s) gates every tile, so
+            // there is nothing to overlap with: the exchange simply precedes the kernel.
+            CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
+        } else if (sched == CG_SCHED_CLASSIC) {
+            // The reference's structure (utils.c:45-62): post the exchange, run the
+            // stencil on the rows that need no halo, wait, then do the edge rows.  The
+            // exchange goes to its own stream; events express the fork and the join.
+            split = a.rt_total >= 3;
+            if (split) {
+                HIPCHK(hipEventRecord(c->ev_fork, s));
+                HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
+                CGCHK(comm_rc(c, c->comm->exchange_rows(c->comm_stream, c->d[c->dcur], c->rows, c->G,
+                                                        c->halo_d[c->dcur][0], c->halo_d[c->dcur][1])));
+                HIPCHK(hipEventRecord(c->ev_halo, c->comm_stream));
+            } else {
+                CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->d[c->dcur], c->rows, c->G, c->halo_d[c->dcur][0],
+                                                        c->halo_d[c->dcur][1])));
+            }
+        }
+        // (first iteration of a fused schedule: d0's halo rows are a closed form, set at init)
     }
     if (fuse) {
         const int in = c->dcur, out = c->dcur ^ 1;
@@ -311,8 +338,19 @@ int enqueue_iteration(cg_ctx *c, bool first)
         a.d_in = c->d[c->dcur];
         a.d_top = c->has_top() ? c->halo_d[c->dcur][0] : nullptr;
         a.d_bot = c->has_bot() ? c->halo_d[c->dcur][1] : nullptr;
-        if (sched == CG_SCHED_FUSED_NOQ) launch_stencil<0, false>(t, a, s);
-        else launch_stencil<0, true>(t, a, s);
+        if (sched == CG_SCHED_FUSED_NOQ) {
+            launch_stencil<0, false>(t, a, s);
+        } else if (!split) {
+            launch_stencil<0, true>(t, a, s);
+        } else {
+            StencilArgs in = a;                       // row tiles 1 .. rt_total-2: no halo row involved
+            in.rt_first = 1;
+            launch_stencil<0, true>(t, in, s, a.rt_total - 2);
+            HIPCHK(hipStreamWaitEvent(s, c->ev_halo, 0));
+            StencilArgs ed = a;                       // first and last row tile, after the halos landed
+            ed.edge_pair = 1;
+            launch_stencil<0, true>(t, ed, s, 2);
+        }
     }
     HIPCHK(hipGetLastError());
     CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0));
@@ -493,6 +531,7 @@ int cg_stencil(int device, long G, long row0, long rows, const double *d, const 
     a.d_in = d; a.d_top = row0 > 0 ? top : nullptr; a.d_bot = row0 + rows < G ? bot : nullptr;
     a.q = q; a.partials = sc->partials; a.sc = nullptr;
     a.G = G; a.rows = rows; a.row0 = row0; a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = 1;
+    a.rt_first = 0; a.rt_total = (int)(t.ntiles / t.nstrips); a.edge_pair = 0;
     launch_stencil<0, true>(t, a, sc->stream);
     HIPCHK(hipGetLastError());
     if (dq_host) {
@@ -604,8 +643,11 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
         for (int s = 0; s < 2; ++s) alloc(&c->halo_d[b][s], (size_t)G * sizeof(double));
     alloc(&c->halo_g[0], (size_t)G * sizeof(double));
     alloc(&c->halo_g[1], (size_t)G * sizeof(double));
-    if (rc == CG_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
-        rc = fail(CG_ERR_HIP, "hipStreamCreate failed");
+    if (rc == CG_OK && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+                        hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming) != hipSuccess))
+        rc = fail(CG_ERR_HIP, "creating the context's streams and events failed");
     if (rc == CG_OK && hipHostMalloc(reinterpret_cast<void **>(&c->host_sc), sizeof(Scalars), hipHostMallocDefault) != hipSuccess)
         rc = fail(CG_ERR_HIP, "hipHostMalloc failed");
     if (rc != CG_OK) { cg_destroy(c); return rc; }
@@ -629,6 +671,9 @@ int cg_destroy(cg_ctx *c)
         for (int s = 0; s < 2; ++s) (void)hipFree(c->halo_d[b][s]);
     (void)hipFree(c->halo_g[0]); (void)hipFree(c->halo_g[1]);
     if (c->host_sc) (void)hipHostFree(c->host_sc);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return CG_OK;
@@ -649,7 +694,7 @@ int cg_set_option(cg_ctx *c, int key, long value)
         c->tile_h = value; break;
     case CG_OPT_GRAPH_ITERS:
         if (value < 0) return fail(CG_ERR_ARG, "graph length must be >= 0");
-        c->graph_iters = value; break;
+        c->graph_iters = value; c->graph_explicit = true; break;
     case CG_OPT_XCD_REMAP: c->remap = value ? 1 : 0; break;
     case CG_OPT_FLAT_BLOCKS:
         if (value < 0 || value > (1 << 20)) return fail(CG_ERR_ARG, "flat block count out of range");
@@ -710,13 +755,18 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     }
     // graph of the steady-state iteration body (set-up, outside the timed region)
     long glen = c->graph_iters;
+    // Multi-rank: RCCL calls can be captured, but a capture that fails on some rank would
+    // take the whole job down, so a graph is used there only when asked for explicitly;
+    // the host-staged transport synchronises the stream and cannot be captured at all.
+    if (c->nranks > 1 && (!c->graph_explicit || !c->comm->stream_ordered())) glen = 0;
     if (glen > 0 && max_iters - 1 >= glen) {
         if (!c->graph || c->graph_sched != sched || c->graph_reduce != c->reduce || c->graph_dcur != c->dcur)
             CGCHK(build_graph(c, glen));
     } else {
         glen = 0;
     }
-    if (c->graph) glen = c->graph_len;
+    if (glen > 0 && c->graph) glen = c->graph_len;
+    if (glen == 0) drop_graph(c);
     HIPCHK(hipStreamSynchronize(s));
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -731,6 +781,7 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         }
         CGCHK(enqueue_dot_finish(c, c->g, c->g, c->partials, fb, 2, rtol));
     }
+    const int dcur_start = c->dcur;
     long launched = 0;
     bool stopped = false;
     // Iteration 0 runs eagerly: the fused schedules have no d update to fold in yet.
@@ -761,7 +812,7 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     // iterations skipped because the stop rule fired did not flip anything.
     if (sched != CG_SCHED_CLASSIC) {
         const long executed = (long)h.iter;
-        c->dcur = (executed >= 1) ? (int)((executed - 1) & 1) : 0;
+        c->dcur = (executed >= 1) ? (dcur_start ^ (int)((executed - 1) & 1)) : dcur_start;
         c->pending_dupdate = executed >= 1;
         CGCHK(flush_pending_dupdate(c));
         HIPCHK(hipStreamSynchronize(s));
@@ -888,7 +939,7 @@ int cg_comm_unique_id(void *id128)
 {
     if (!id128) return fail(CG_ERR_ARG, "cg_comm_unique_id: NULL");
     char msg[256];
-    if (cg::Comm::unique_id(id128, msg, sizeof msg) != 0) return fail(CG_ERR_COMM, "%s", msg);
+    if (cg::RcclComm::unique_id(id128, msg, sizeof msg) != 0) return fail(CG_ERR_COMM, "%s", msg);
     return CG_OK;
 }
 
@@ -900,7 +951,23 @@ int cg_comm_init(cg_ctx *c, const void *id128)
     delete c->comm;
     c->comm = nullptr;
     char msg[256];
-    cg::Comm *comm = cg::Comm::create(id128, c->rank, c->nranks, c->has_top(), c->has_bot(), msg, sizeof msg);
+    cg::Comm *comm = cg::RcclComm::create(id128, c->rank, c->nranks, c->has_top(), c->has_bot(), msg, sizeof msg);
+    if (!comm) return fail(CG_ERR_COMM, "%s", msg);
+    c->comm = comm;
+    drop_graph(c);
+    return CG_OK;
+}
+
+int cg_comm_init_host(cg_ctx *c, cg_exchange_fn exchange, cg_allgather_fn allgather, void *user)
+{
+    if (!c || !exchange || !allgather) return fail(CG_ERR_ARG, "cg_comm_init_host: NULL argument");
+    if (c->nranks < 2) return fail(CG_ERR_STATE, "cg_comm_init_host on a single-rank context");
+    CGCHK(select_device(c->device));
+    delete c->comm;
+    c->comm = nullptr;
+    char msg[256];
+    cg::Comm *comm = cg::HostComm::create(exchange, allgather, user, c->rank, c->nranks, c->G, c->has_top(), c->has_bot(),
+                                          msg, sizeof msg);
     if (!comm) return fail(CG_ERR_COMM, "%s", msg);
     c->comm = comm;
     drop_graph(c);

@@ -60,7 +60,12 @@ SIGNATURES = {
     "cg_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp]),
     "cg_comm_unique_id": (C.c_int, [C.c_void_p]),
     "cg_comm_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cg_comm_init_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
+
+# callback prototypes of cg_comm_init_host (all pointers are host pointers)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p)
 
 _lib = None
 

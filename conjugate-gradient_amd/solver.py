@@ -160,6 +160,17 @@ class CGSolver:
         buf = C.create_string_buffer(bytes(id128), 128)
         _l.check(self._lib.cg_comm_init(self._ctx, buf))
 
+    def comm_init_host(self, transport):
+        """Carry halo rows and dot-product partials over `transport` (dist.RowTransport) instead of RCCL.
+
+        Host-staged and synchronous: for running the multi-rank path with several
+        processes on one GPU, or where RCCL is unavailable.
+        """
+        from .dist import make_callbacks
+        self._callbacks = make_callbacks(transport)          # keep the ctypes thunks alive
+        ex, ag = self._callbacks
+        _l.check(self._lib.cg_comm_init_host(self._ctx, C.cast(ex, C.c_void_p), C.cast(ag, C.c_void_p), None))
+
     # -- solve -----------------------------------------------------------
     def init_problem(self):
         _l.check(self._lib.cg_init_problem(self._ctx))

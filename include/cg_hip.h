@@ -145,6 +145,22 @@ int cg_time_kernel(cg_ctx *ctx, int which, int reps, double *ms_per_launch, doub
 int cg_comm_unique_id(void *id128);
 int cg_comm_init(cg_ctx *ctx, const void *id128);
 
+/* The same exchanges carried by the caller instead of RCCL: the library stages
+ * the rows / the scalar through pinned host memory and calls these functions
+ * (all pointers are HOST pointers; return 0 on success).  Synchronous and slow --
+ * meant for running every multi-rank code path with several processes that
+ * share one GPU (tests), and as a fallback where RCCL is unavailable.
+ *   exchange: send_up -> rank-1, send_down -> rank+1, and fill recv_top from
+ *             rank-1's send_down, recv_bot from rank+1's send_up; `count` doubles
+ *             each; a NULL pair means there is no neighbour on that side
+ *             (utils.c:231-248).
+ *   allgather: all[r] = rank r's `mine`, r = 0..nranks-1 (stands in for the
+ *             MPI_Allreduce of utils.c:380; the sum is then formed in rank order). */
+typedef int (*cg_exchange_fn)(void *user, const double *send_up, const double *send_down,
+                              double *recv_top, double *recv_bot, long count);
+typedef int (*cg_allgather_fn)(void *user, double mine, double *all);
+int cg_comm_init_host(cg_ctx *ctx, cg_exchange_fn exchange, cg_allgather_fn allgather, void *user);
+
 #ifdef __cplusplus
 }
 #endif
