@@ -48,6 +48,26 @@ for k in sorted(dur, key=lambda k: -sum(dur[k])):
     gbs = (rd + wr) / mean_ns if rd == rd and wr == wr else float("nan")
     lines.append(f"| `{short(k)}` | {len(dur[k])} | {mean_ns/1e3:.1f} ({100*sum(dur[k])/tot:.1f}%) | {rd/1e6:.1f} | {wr/1e6:.1f} | {gbs:.0f} |")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+
+# machine-readable traffic of the two hot kernels, keyed the way bench.py names them
+import json, re
+cfg = {}
+m = re.search(r'"grid": (\d+).*?"schedule": "(\w+)"', open(os.path.join(src, "trace.log")).read())
+if m:
+    cfg = {"grid": int(m.group(1)), "schedule": m.group(2)}
+role = {"1": "stencil", "0": "stencil", "2": "update"}
+kern = {}
+for k in dur:
+    mm = re.match(r"void cg::k_stencil<\d+, (\d), \w+, \d+>", k)
+    name = role.get(mm.group(1)) if mm else ("update" if "k_update" in k else "dupdate" if "k_dupdate" in k else None)
+    if name is None or not fetch.get(k) or not write.get(k) or len(dur[k]) < 10:
+        continue
+    rd = 2 * 1024 * sum(fetch[k]) / len(fetch[k])
+    wr = 1024 * sum(write[k]) / len(write[k])
+    kern[name] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+                  "mean_us": sum(dur[k]) / len(dur[k]) / 1e3, "kernel": short(k)}
+json.dump(dict(cfg, tag=tag, kernels=kern, note="FETCH_SIZE x2 x1024 + WRITE_SIZE x1024 (gfx950)"),
+          open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 st = find("trace", "*kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats.csv"))
