@@ -7,9 +7,10 @@ hyphen, so import it with importlib.import_module("conjugate-gradient_amd").
 """
 from . import lib
 from .lib import (CGError, REDUCE_FAST, REDUCE_STRICT, SCHED_CLASSIC, SCHED_FUSED, SCHED_FUSED_NOQ,
-                  VEC_U, VEC_G, VEC_D, VEC_Q, SCHED_BYTES_PER_POINT, SCHED_NAMES, device_count)
+                  VEC_U, VEC_G, VEC_D, VEC_Q, SCHED_BYTES_PER_POINT, SCHED_NAMES, device_count,
+                  STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL)
 from .solver import CGSolver, DeviceVector, SolveResult, init_d, init_g, stencil, dot, axpy, xpay
 
 __all__ = ["lib", "CGError", "CGSolver", "DeviceVector", "SolveResult", "init_d", "init_g", "stencil", "dot",
            "axpy", "xpay", "device_count", "REDUCE_FAST", "REDUCE_STRICT", "SCHED_CLASSIC", "SCHED_FUSED",
-           "SCHED_FUSED_NOQ", "VEC_U", "VEC_G", "VEC_D", "VEC_Q", "SCHED_BYTES_PER_POINT", "SCHED_NAMES"]
+           "SCHED_FUSED_NOQ", "STRICT_AUTO", "STRICT_REPLAY", "STRICT_PARALLEL", "VEC_U", "VEC_G", "VEC_D", "VEC_Q", "SCHED_BYTES_PER_POINT", "SCHED_NAMES"]

@@ -1,0 +1,351 @@
+// Bit-exact parallel evaluation of the reference's dot product.
+//
+// The reference adds the products to ONE accumulator in index order
+// (utils.c:372-379): s <- fl(s + fl(v[k]*w[k])), k = 0..N-1.  That recurrence is
+// not associative, and replaying it literally costs one dependent fp64 add per
+// element (k_dot_strict: ~1 s for 2.7e8 elements).  This file computes the very
+// same bits in parallel.
+//
+// Idea.  While the accumulator stays inside one binade [2^e, 2^(e+1)) its ulp is
+// the constant u = 2^(e-52), and with S = s/u (an integer in [2^52, 2^53)) and
+// x = p/u (exact: a power-of-two scaling)
+//        fl(s + p) / u  =  RN(S + x)  =  S + RN(x)        unless x is a tie (x = m + 1/2),
+// i.e. inside a binade the recurrence adds INTEGERS, which is associative.  So:
+//   A. approximate sums of chunks of 1024 consecutive products (any order);
+//   B. their exclusive prefix gives, per chunk, a guess e of the accumulator's
+//      exponent when the recurrence reaches that chunk;
+//   C. per chunk, under the hypothesis "the accumulator stays in binade e": the
+//      integer sum D of RN(x_k), and the min / max of its running value (to verify the
+//      hypothesis later); ties, huge addends and NaNs mark the chunk unusable;
+//   D. groups of 64 chunks with one common guess are composed in order
+//      ((D,mn,mx) o (D',mn',mx') = (D+D', min(mn, D+mn'), max(mx, D+mx')));
+//   E. ONE wavefront then walks the groups in order with the true accumulator s:
+//      it scans 64 summaries at a time, accepts the longest prefix whose hypothesis
+//      holds for the actual s (right exponent, running value never leaves
+//      [2^52+1, 2^53-1], no flag), and where that fails descends to the chunks of the
+//      group and, for a failing chunk, to the literal element-by-element recurrence.
+// Failures are rare: each binade crossing of the accumulator (a few dozen per dot
+// product), the leading zeros, and ties (~2^-29 per element).  The margins of one ulp
+// at both ends of the binade make the integer model exact: a running value of at
+// least 2^52+1 means the unrounded sum was at least 2^52+1/2, still inside the binade.
+// Every step is either exact integer arithmetic in fp64 (|values| < 2^53) or the
+// literal recurrence, so the result is bit-identical to the CPU loop for ANY input.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+
+namespace cg {
+namespace exact {
+
+constexpr int kChunk = 1024;          // elements per chunk = one wavefront x 16
+constexpr int kPerLane = kChunk / 64;
+constexpr int kGroup = 64;            // chunks per group = one wavefront of summaries
+constexpr int kAnyExp = INT_MAX;      // summary valid under every hypothesis (all addends are zero)
+constexpr int kNoExp = INT_MIN;       // no usable guess
+
+struct Summary {
+    double D;         // sum of the rounded addends, in ulps of the hypothesised binade
+    double mn, mx;    // extremes of the running value of D (the empty prefix, 0, included)
+    int e;            // hypothesised exponent of the accumulator, or kAnyExp
+    int bad;          // the summary must not be used
+};
+
+__device__ __forceinline__ Summary identity()
+{
+    Summary s; s.D = 0.0; s.mn = 0.0; s.mx = 0.0; s.e = kAnyExp; s.bad = 0;
+    return s;
+}
+
+// a happens before b
+__device__ __forceinline__ Summary compose(const Summary &a, const Summary &b)
+{
+    Summary r;
+    r.D = a.D + b.D;
+    r.mn = fmin(a.mn, a.D + b.mn);
+    r.mx = fmax(a.mx, a.D + b.mx);
+    r.bad = a.bad | b.bad | ((a.e != kAnyExp && b.e != kAnyExp && a.e != b.e) ? 1 : 0);
+    r.e = (a.e != kAnyExp) ? a.e : b.e;
+    return r;
+}
+
+__device__ __forceinline__ Summary shfl_down(const Summary &s, int off)
+{
+    Summary r;
+    r.D = __shfl_down(s.D, off, 64); r.mn = __shfl_down(s.mn, off, 64); r.mx = __shfl_down(s.mx, off, 64);
+    r.e = __shfl_down(s.e, off, 64); r.bad = __shfl_down(s.bad, off, 64);
+    return r;
+}
+__device__ __forceinline__ Summary shfl_up(const Summary &s, int off)
+{
+    Summary r;
+    r.D = __shfl_up(s.D, off, 64); r.mn = __shfl_up(s.mn, off, 64); r.mx = __shfl_up(s.mx, off, 64);
+    r.e = __shfl_up(s.e, off, 64); r.bad = __shfl_up(s.bad, off, 64);
+    return r;
+}
+
+// Ordered reduction over the wavefront, lane 0 first; result valid in lane 0.
+__device__ __forceinline__ Summary wave_compose(Summary cur)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Summary nxt = shfl_down(cur, off);
+        if ((lane & (2 * off - 1)) == 0) cur = compose(cur, nxt);
+    }
+    return cur;
+}
+
+// Exponent of a finite non-zero normal double, else kNoExp.
+__device__ __forceinline__ int exponent_of(double s)
+{
+    if (!(fabs(s) >= 0x1p-1021) || !(fabs(s) <= 0x1.fffffffffffffp+1023)) return kNoExp;
+    return ilogb(s);
+}
+
+// ---- A: approximate chunk sums ------------------------------------------------
+__global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v, const double *__restrict__ w,
+                                                   long count, long nchunks, double *__restrict__ approx)
+{
+    const int lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const long base = c * kChunk;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k) {
+        const long i = base + (long)k * 64 + lane;
+        if (i < count) acc += v[i] * w[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) approx[c] = acc;
+}
+
+// ---- B: exclusive prefix of the approximate sums -> exponent guess per chunk -----
+__global__ __launch_bounds__(1024) void k_xs_guess(const double *__restrict__ approx, long nchunks, double start,
+                                                   int *__restrict__ guess)
+{
+    __shared__ double tot[1024];
+    const int t = threadIdx.x;
+    const long per = (nchunks + 1023) / 1024;
+    const long lo = (long)t * per, hi = (lo + per < nchunks) ? lo + per : nchunks;
+    double acc = 0.0;
+    for (long c = lo; c < hi; ++c) acc += approx[c];
+    tot[t] = acc;
+    __syncthreads();
+    if (t == 0) {
+        double run = start;
+        for (int i = 0; i < 1024; ++i) { const double x = tot[i]; tot[i] = run; run += x; }
+    }
+    __syncthreads();
+    double run = tot[t];
+    for (long c = lo; c < hi; ++c) {
+        guess[c] = exponent_of(run);
+        run += approx[c];
+    }
+}
+
+// ---- C: per-chunk integer summaries under the guessed exponent --------------------
+__global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, const double *__restrict__ w,
+                                                  long count, long nchunks, const int *__restrict__ guess,
+                                                  Summary *__restrict__ out)
+{
+    // Products are fetched coalesced (lane-interleaved) and handed to the lanes as 16
+    // CONSECUTIVE elements each through LDS; 18-double rows keep the 16-byte reads of the
+    // 16 lanes of a group on distinct banks.
+    __shared__ __attribute__((aligned(16))) double tile[4][64 * 18];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * 4 + wv;
+    if (c >= nchunks) return;                       // whole wavefront leaves together
+    const long base = c * kChunk;
+    double *T = tile[wv];
+#pragma unroll
+    for (int k = 0; k < kPerLane / 2; ++k) {
+        const int pos = k * 128 + 2 * lane;
+        const long i = base + pos;
+        double p0 = 0.0, p1 = 0.0;
+        if (i < count) p0 = v[i] * w[i];
+        if (i + 1 < count) p1 = v[i + 1] * w[i + 1];
+        double *dst = T + (pos >> 4) * 18 + (pos & 15);
+        dst[0] = p0; dst[1] = p1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double p[kPerLane];
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) p[i] = T[lane * 18 + i];
+
+    const int e = guess[c];
+    const int sh = (e == kNoExp) ? 0 : 52 - e;
+    Summary s = identity();
+    bool nz = false;
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+        const double x = ldexp(p[i], sh);
+        const double r = rint(x);
+        nz |= (p[i] != 0.0);
+        s.bad |= (!(fabs(x) < 0x1p51) || fabs(x - r) == 0.5) ? 1 : 0;
+        s.D += r;
+        s.mn = fmin(s.mn, s.D);
+        s.mx = fmax(s.mx, s.D);
+    }
+    const bool any_nz = __ballot(nz) != 0ull;
+    s.e = e;
+    s = wave_compose(s);
+    if (lane == 0) {
+        if (!any_nz) s = identity();                // adding zeros leaves any accumulator unchanged
+        else if (e == kNoExp) s.bad = 1;
+        out[c] = s;
+    }
+}
+
+// ---- D: groups of 64 chunk summaries -------------------------------------------------
+__global__ __launch_bounds__(256) void k_xs_group(const Summary *__restrict__ in, long nin, Summary *__restrict__ out,
+                                                  long nout)
+{
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nout) return;
+    const long i = g * kGroup + lane;
+    Summary s = (i < nin) ? in[i] : identity();
+    s = wave_compose(s);
+    if (lane == 0) out[g] = s;
+}
+
+// ---- E: the ordered walk ----------------------------------------------------------------
+
+// Does the hypothesis behind `c` hold for an accumulator S (in ulps, |S| in [2^52, 2^53))?
+__device__ __forceinline__ bool holds(const Summary &c, int es, double S)
+{
+    if (c.bad) return false;
+    if (c.e == kAnyExp) return true;                // zeros only
+    if (es == kNoExp || c.e != es) return false;
+    if (S > 0.0) return (S + c.mn >= 0x1p52 + 1.0) && (S + c.mx <= 0x1p53 - 1.0);
+    return (S + c.mx <= -(0x1p52 + 1.0)) && (S + c.mn >= -(0x1p53 - 1.0));
+}
+
+// The literal recurrence over elements [lo, hi): 64 coalesced products at a time, then 64
+// dependent additions replayed identically by every lane.
+__device__ __forceinline__ double replay(const double *v, const double *w, long lo, long hi, double s, int lane)
+{
+    for (long base = lo; base < hi; base += 64) {
+        const long i = base + lane;
+        const double p = (i < hi) ? v[i] * w[i] : 0.0;
+        const int m = (hi - base < 64) ? (int)(hi - base) : 64;
+        if (m == 64) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) s += __shfl(p, l, 64);
+        } else {
+            for (int l = 0; l < m; ++l) s += __shfl(p, l, 64);
+        }
+    }
+    return s;
+}
+
+// Walk up to 64 summaries held one per lane (`mine`; lanes >= n hold nothing), in order,
+// starting from accumulator s.  Returns the index of the first summary that could not be
+// applied (n if all were) and updates s to the accumulator just before it.
+__device__ __forceinline__ int walk(Summary mine, int n, int from, double &s, int lane)
+{
+    const int es = exponent_of(s);
+    const double S = (es == kNoExp) ? 0.0 : ldexp(s, 52 - es);
+    Summary cur = (lane >= from && lane < n) ? mine : identity();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {        // inclusive ordered scan
+        const Summary prev = shfl_up(cur, off);
+        if (lane >= off) cur = compose(prev, cur);
+    }
+    const bool ok = holds(cur, es, S);
+    // validity is monotone along the scan (flags accumulate, extremes only widen)
+    unsigned long long okmask = __ballot(ok && lane >= from && lane < n);
+    unsigned long long want = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) & ~((from >= 64) ? ~0ull : ((1ull << from) - 1ull));
+    const unsigned long long failed = want & ~okmask;
+    const int f = failed ? (int)__builtin_ctzll(failed) : n;
+    if (f > from) {
+        const double D = __shfl(cur.D, f - 1, 64);
+        const int ce = __shfl(cur.e, f - 1, 64);
+        if (ce != kAnyExp) s = ldexp(S + D, es - 52);   // exact: integers below 2^53
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, const double *__restrict__ w, long count,
+                                                const Summary *__restrict__ chunks, long nchunks,
+                                                const Summary *__restrict__ groups, long ngroups, double start,
+                                                double *__restrict__ result)
+{
+    const int lane = threadIdx.x;
+    double s = start;
+    for (long gb = 0; gb < ngroups; gb += 64) {
+        const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
+        const Summary gmine = (lane < ng) ? groups[gb + lane] : identity();
+        int gpos = 0;
+        while (gpos < ng) {
+            const int gf = walk(gmine, ng, gpos, s, lane);
+            if (gf >= ng) break;
+            // group gb+gf does not apply as a whole: walk its chunks
+            const long cb = (gb + gf) * kGroup;
+            const int nc = (nchunks - cb < 64) ? (int)(nchunks - cb) : 64;
+            const Summary cmine = (lane < nc) ? chunks[cb + lane] : identity();
+            int cpos = 0;
+            while (cpos < nc) {
+                const int cf = walk(cmine, nc, cpos, s, lane);
+                if (cf >= nc) break;
+                const long lo = (cb + cf) * kChunk;
+                const long hi = (lo + kChunk < count) ? lo + kChunk : count;
+                s = replay(v, w, lo, hi, s, lane);
+                cpos = cf + 1;
+            }
+            gpos = gf + 1;
+        }
+    }
+    if (lane == 0) *result = s;
+}
+
+// Workspace for `count` elements.
+struct Workspace {
+    double *approx = nullptr;
+    int *guess = nullptr;
+    Summary *chunks = nullptr, *groups = nullptr;
+    long cap_chunks = 0;
+
+    static long chunks_for(long count) { return (count + kChunk - 1) / kChunk; }
+    hipError_t reserve(long count)
+    {
+        const long nc = chunks_for(count);
+        if (nc <= cap_chunks) return hipSuccess;
+        release();
+        const long ng = (nc + kGroup - 1) / kGroup;
+        hipError_t e;
+        if ((e = hipMalloc(&approx, (size_t)nc * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&guess, (size_t)nc * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMalloc(&chunks, (size_t)nc * sizeof(Summary))) != hipSuccess) return e;
+        if ((e = hipMalloc(&groups, (size_t)ng * sizeof(Summary))) != hipSuccess) return e;
+        cap_chunks = nc;
+        return hipSuccess;
+    }
+    void release()
+    {
+        (void)hipFree(approx); (void)hipFree(guess); (void)hipFree(chunks); (void)hipFree(groups);
+        approx = nullptr; guess = nullptr; chunks = nullptr; groups = nullptr; cap_chunks = 0;
+    }
+};
+
+// result <- the reference's sequential dot product of v and w started from `start`.
+// Stream-ordered; the workspace must have been reserved for `count`.
+inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
+                    double *result)
+{
+    const long nc = Workspace::chunks_for(count);
+    const long ng = (nc + kGroup - 1) / kGroup;
+    const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4);
+    hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, ws.approx);
+    hipLaunchKernelGGL(k_xs_guess, dim3(1), dim3(1024), 0, s, ws.approx, nc, start, ws.guess);
+    hipLaunchKernelGGL(k_xs_chunk, dim3(cb), dim3(256), 0, s, v, w, count, nc, ws.guess, ws.chunks);
+    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
+    hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, start, result);
+}
+
+} // namespace exact
+} // namespace cg

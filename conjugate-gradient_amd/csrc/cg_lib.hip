@@ -8,6 +8,7 @@
 #include "cg_kernels.hpp"
 #include "../../include/cg_hip.h"
 #include "cg_comm.hpp"
+#include "cg_exact.hpp"
 
 #include <chrono>
 #include <cstdarg>
@@ -71,8 +72,20 @@ struct DeviceScratch {
     double *partials = nullptr;            // kMaxPartials doubles
     Scalars *sc = nullptr;
     double *slot = nullptr;                // strict-dot result
+    cg::exact::Workspace xs;               // workspace of the parallel strict-order dot product
     bool ready = false;
 };
+
+// Strict-order dot product: below this many elements the literal one-wavefront replay is
+// as fast as the five-kernel parallel evaluation.
+constexpr long kExactMin = 1L << 15;
+// `strict` argument of cg_dot / value of CG_OPT_STRICT_IMPL: how the reference's order is evaluated.
+enum { kStrictAuto = 1, kStrictReplay = 2, kStrictParallel = 3 };
+
+bool use_parallel_strict(int impl, long count)
+{
+    return impl == kStrictParallel || (impl != kStrictReplay && count >= kExactMin);
+}
 constexpr long kMaxPartials = 1 << 16;
 DeviceScratch g_scratch[kMaxDevices];
 std::mutex g_scratch_mu;
@@ -193,6 +206,8 @@ struct cg_ctx {
     long npart = 0;
     Scalars *sc = nullptr;
     double *strict_slot = nullptr;
+    cg::exact::Workspace xs;              // strict order, parallel evaluation
+    int strict_impl = kStrictAuto;
     double *hist = nullptr;
     long hist_cap = 0;
     long hist_len = 0;
@@ -256,7 +271,10 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
     const double *src = nullptr;
     if (c->reduce == CG_REDUCE_STRICT) {
         if (c->nranks > 1) return fail(CG_ERR_STATE, "strict reduction order is single-GPU only");
-        hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, c->strict_slot);
+        if (use_parallel_strict(c->strict_impl, c->count))
+            cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, c->strict_slot);     // workspace reserved by cg_solve
+        else
+            hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, c->strict_slot);
         src = c->strict_slot;
     } else if (c->nranks > 1) {
         // local fixed-order sum -> all ranks' sums (RCCL all-gather) -> rank-order sum
@@ -555,7 +573,12 @@ int cg_dot(int device, long count, const double *v, const double *w, int strict,
     DeviceScratch *sc;
     CGCHK(get_scratch(device, &sc));
     if (strict) {
-        hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, sc->stream, v, w, count, start, sc->slot);
+        if (use_parallel_strict(strict, count)) {
+            HIPCHK(sc->xs.reserve(count));
+            cg::exact::enqueue(sc->stream, sc->xs, v, w, count, start, sc->slot);
+        } else {
+            hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, sc->stream, v, w, count, start, sc->slot);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(result_host, sc->slot, sizeof(double), hipMemcpyDeviceToHost, sc->stream));
         HIPCHK(hipStreamSynchronize(sc->stream));
@@ -664,6 +687,7 @@ int cg_destroy(cg_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     delete c->comm;
+    c->xs.release();
     (void)hipFree(c->u); (void)hipFree(c->g); (void)hipFree(c->q);
     (void)hipFree(c->d[0]); (void)hipFree(c->d[1]);
     (void)hipFree(c->partials); (void)hipFree(c->strict_slot); (void)hipFree(c->sc); (void)hipFree(c->hist);
@@ -702,6 +726,9 @@ int cg_set_option(cg_ctx *c, int key, long value)
     case CG_OPT_PREFETCH:
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(CG_ERR_ARG, "prefetch depth must be 1, 2, 4 or 8");
         c->prefetch = (int)value; break;
+    case CG_OPT_STRICT_IMPL:
+        if (value < kStrictAuto || value > kStrictParallel) return fail(CG_ERR_ARG, "strict implementation must be 1, 2 or 3");
+        c->strict_impl = (int)value; break;
     default: return fail(CG_ERR_ARG, "unknown option key %d", key);
     }
     drop_graph(c);
@@ -744,6 +771,11 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     if (c->nranks > 1 && !c->comm) return fail(CG_ERR_STATE, "multi-rank context without cg_comm_init");
     hipStream_t s = c->stream;
 
+    if (c->reduce == CG_REDUCE_STRICT && use_parallel_strict(c->strict_impl, c->count)) {
+        const long before = c->xs.cap_chunks;
+        HIPCHK(c->xs.reserve(c->count));
+        if (c->xs.cap_chunks != before) drop_graph(c);      // captured nodes hold the old workspace
+    }
     // history buffer (set-up, outside the timed region)
     if (c->hist_cap < max_iters) {
         drop_graph(c);                                  // the graph's k_finish nodes hold the old pointer

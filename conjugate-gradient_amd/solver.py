@@ -85,8 +85,8 @@ def stencil(G, row0, rows, d, q, top=None, bot=None, device=0, want_dq=False):
 
 def dot(count, v, w, strict=False, start=0.0, device=0):
     """sum v[k]*w[k]: the local part of dot (utils.c:368-379)."""
-    r = C.c_double(0.0)
-    _l.check(_l.load().cg_dot(device, count, _p(v), _p(w), 1 if strict else 0, start, C.byref(r)))
+    r = C.c_double(0.0)          # strict: False/0 fast order, True/1 auto, 2 literal replay, 3 parallel evaluation
+    _l.check(_l.load().cg_dot(device, count, _p(v), _p(w), int(strict), start, C.byref(r)))
     return r.value
 
 
@@ -124,7 +124,7 @@ class CGSolver:
         _l.check(self._lib.cg_set_option(self._ctx, key, int(value)))
 
     def configure(self, reduce=None, schedule=None, tile_h=None, graph_iters=None, xcd_remap=None,
-                  flat_blocks=None, prefetch=None):
+                  flat_blocks=None, prefetch=None, strict_impl=None):
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
@@ -143,6 +143,8 @@ class CGSolver:
             self.set_option(_l.OPT_FLAT_BLOCKS, flat_blocks)
         if prefetch is not None:
             self.set_option(_l.OPT_PREFETCH, prefetch)
+        if strict_impl is not None:
+            self.set_option(_l.OPT_STRICT_IMPL, strict_impl)
         return self
 
     @property

@@ -57,9 +57,15 @@ int cg_init_g(int device, long count, const double *d, double *g);
  * returns d.q accumulated in the fast order (fused, one pass).               */
 int cg_stencil(int device, long G, long row0, long rows, const double *d,
                const double *top, const double *bot, double *q, double *dq_host);
-/* *result_host = sum v[k]*w[k], k = 0..count-1.  strict = 1: one accumulator in
+/* *result_host = sum v[k]*w[k], k = 0..count-1.  strict != 0: one accumulator in
  * index order starting from `start` (bit-identical to utils.c:372-379);
  * strict = 0: the documented fast order (start is added last).
+ * The strict order has two evaluations that return the same bits for any input:
+ * strict = 2 replays the recurrence literally on one wavefront (one dependent
+ * add per element); strict = 3 evaluates it in parallel (inside a binade the
+ * recurrence adds integers, which is associative; binade crossings, ties and
+ * the leading zeros fall back to the literal replay, a chunk at a time);
+ * strict = 1 picks the parallel one from 32768 elements up.
  * Replaces the local part of dot, utils.c:368-379.                           */
 int cg_dot(int device, long count, const double *v, const double *w, int strict,
            double start, double *result_host);
@@ -88,6 +94,8 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_XCD_REMAP   5   /* 1 = XCD-aware tile order (default), 0 = plain order  */
 #define CG_OPT_FLAT_BLOCKS 6   /* workgroups of the flat (1-D) kernels, 0 = auto       */
 #define CG_OPT_PREFETCH    7   /* rows of loads each thread keeps in flight: 1, 2, 4 (default) or 8 */
+#define CG_OPT_STRICT_IMPL 8   /* how the strict order is evaluated: 1 = auto (default), 2 = literal
+                                  one-accumulator replay, 3 = parallel evaluation (same bits, see cg_dot) */
 
 /* A context owns the row block [row0, row0+rows) x (n+1) of u, g, d, q on
  * `device`.  Single GPU: row0 = 0, rows = n+1, rank 0 of 1.                  */
