@@ -11,19 +11,22 @@
 // x = p/u (exact: a power-of-two scaling)
 //        fl(s + p) / u  =  RN(S + x)  =  S + RN(x)        unless x is a tie (x = m + 1/2),
 // i.e. inside a binade the recurrence adds INTEGERS, which is associative.  So:
-//   A. approximate sums of chunks of 1024 consecutive products (any order);
-//   B. their exclusive prefix gives, per chunk, a guess e of the accumulator's
-//      exponent when the recurrence reaches that chunk;
-//   C. per chunk, under the hypothesis "the accumulator stays in binade e": the
-//      integer sum D of RN(x_k), and the min / max of its running value (to verify the
-//      hypothesis later); ties, huge addends and NaNs mark the chunk unusable;
-//   D. groups of 64 chunks with one common guess are composed in order
+//   A. approximate sums of chunks of 1024 consecutive products (any order), and of
+//      groups of 64 chunks; an exclusive scan of the group sums;
+//   B. per chunk: from those, a guess e of the accumulator's exponent when the
+//      recurrence reaches the chunk; then, under the hypothesis "the accumulator stays
+//      in binade e", the integer sum D of RN(x_k) and the min / max of its running
+//      value (to verify the hypothesis later); ties, huge addends and NaNs mark the
+//      chunk unusable;
+//   C. groups of 64 chunks with one common guess are composed in order
 //      ((D,mn,mx) o (D',mn',mx') = (D+D', min(mn, D+mn'), max(mx, D+mx')));
-//   E. ONE wavefront then walks the groups in order with the true accumulator s:
+//   D. ONE wavefront then walks the groups in order with the true accumulator s:
 //      it scans 64 summaries at a time, accepts the longest prefix whose hypothesis
 //      holds for the actual s (right exponent, running value never leaves
 //      [2^52+1, 2^53-1], no flag), and where that fails descends to the chunks of the
-//      group and, for a failing chunk, to the literal element-by-element recurrence.
+//      group, then to 16-element pieces of the failing chunk (summarised on the spot
+//      under the accumulator's actual exponent), and finally to the literal
+//      element-by-element recurrence for the one piece that does not fit.
 // Failures are rare: each binade crossing of the accumulator (a few dozen per dot
 // product), the leading zeros, and ties (~2^-29 per element).  The margins of one ulp
 // at both ends of the binade make the integer model exact: a running value of at
@@ -42,6 +45,8 @@ constexpr int kPerLane = kChunk / 64;
 constexpr int kGroup = 64;            // chunks per group = one wavefront of summaries
 constexpr int kAnyExp = INT_MAX;      // summary valid under every hypothesis (all addends are zero)
 constexpr int kNoExp = INT_MIN;       // no usable guess
+
+typedef double xv2 __attribute__((ext_vector_type(2)));
 
 struct Summary {
     double D;         // sum of the rounded addends, in ulps of the hypothesised binade
@@ -102,81 +107,9 @@ __device__ __forceinline__ int exponent_of(double s)
     return ilogb(s);
 }
 
-// ---- A: approximate chunk sums ------------------------------------------------
-__global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v, const double *__restrict__ w,
-                                                   long count, long nchunks, double *__restrict__ approx)
+// Summary of kPerLane consecutive addends under the hypothesis "exponent e".
+__device__ __forceinline__ Summary piece_summary(const double (&p)[kPerLane], int e)
 {
-    const int lane = threadIdx.x & 63;
-    const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= nchunks) return;
-    const long base = c * kChunk;
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < kPerLane; ++k) {
-        const long i = base + (long)k * 64 + lane;
-        if (i < count) acc += v[i] * w[i];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) approx[c] = acc;
-}
-
-// ---- B: exclusive prefix of the approximate sums -> exponent guess per chunk -----
-__global__ __launch_bounds__(1024) void k_xs_guess(const double *__restrict__ approx, long nchunks, double start,
-                                                   int *__restrict__ guess)
-{
-    __shared__ double tot[1024];
-    const int t = threadIdx.x;
-    const long per = (nchunks + 1023) / 1024;
-    const long lo = (long)t * per, hi = (lo + per < nchunks) ? lo + per : nchunks;
-    double acc = 0.0;
-    for (long c = lo; c < hi; ++c) acc += approx[c];
-    tot[t] = acc;
-    __syncthreads();
-    if (t == 0) {
-        double run = start;
-        for (int i = 0; i < 1024; ++i) { const double x = tot[i]; tot[i] = run; run += x; }
-    }
-    __syncthreads();
-    double run = tot[t];
-    for (long c = lo; c < hi; ++c) {
-        guess[c] = exponent_of(run);
-        run += approx[c];
-    }
-}
-
-// ---- C: per-chunk integer summaries under the guessed exponent --------------------
-__global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, const double *__restrict__ w,
-                                                  long count, long nchunks, const int *__restrict__ guess,
-                                                  Summary *__restrict__ out)
-{
-    // Products are fetched coalesced (lane-interleaved) and handed to the lanes as 16
-    // CONSECUTIVE elements each through LDS; 18-double rows keep the 16-byte reads of the
-    // 16 lanes of a group on distinct banks.
-    __shared__ __attribute__((aligned(16))) double tile[4][64 * 18];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long c = (long)blockIdx.x * 4 + wv;
-    if (c >= nchunks) return;                       // whole wavefront leaves together
-    const long base = c * kChunk;
-    double *T = tile[wv];
-#pragma unroll
-    for (int k = 0; k < kPerLane / 2; ++k) {
-        const int pos = k * 128 + 2 * lane;
-        const long i = base + pos;
-        double p0 = 0.0, p1 = 0.0;
-        if (i < count) p0 = v[i] * w[i];
-        if (i + 1 < count) p1 = v[i + 1] * w[i + 1];
-        double *dst = T + (pos >> 4) * 18 + (pos & 15);
-        dst[0] = p0; dst[1] = p1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double p[kPerLane];
-#pragma unroll
-    for (int i = 0; i < kPerLane; ++i) p[i] = T[lane * 18 + i];
-
-    const int e = guess[c];
     const int sh = (e == kNoExp) ? 0 : 52 - e;
     Summary s = identity();
     bool nz = false;
@@ -190,17 +123,131 @@ __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, 
         s.mn = fmin(s.mn, s.D);
         s.mx = fmax(s.mx, s.D);
     }
-    const bool any_nz = __ballot(nz) != 0ull;
+    if (!nz) return identity();                     // adding zeros leaves a non-zero accumulator unchanged
     s.e = e;
-    s = wave_compose(s);
-    if (lane == 0) {
-        if (!any_nz) s = identity();                // adding zeros leaves any accumulator unchanged
-        else if (e == kNoExp) s.bad = 1;
-        out[c] = s;
+    if (e == kNoExp) s.bad = 1;
+    return s;
+}
+
+// Two consecutive products starting at even index i (zero beyond `count`).
+__device__ __forceinline__ void product_pair(const double *__restrict__ v, const double *__restrict__ w, long i,
+                                             long count, bool vec, double &p0, double &p1)
+{
+    if (vec && i + 1 < count) {
+        const xv2 a = __builtin_nontemporal_load(reinterpret_cast<const xv2 *>(v + i));
+        const xv2 b = __builtin_nontemporal_load(reinterpret_cast<const xv2 *>(w + i));
+        p0 = a.x * b.x; p1 = a.y * b.y;
+    } else {
+        p0 = (i < count) ? v[i] * w[i] : 0.0;
+        p1 = (i + 1 < count) ? v[i + 1] * w[i + 1] : 0.0;
     }
 }
 
-// ---- D: groups of 64 chunk summaries -------------------------------------------------
+// ---- A: approximate chunk sums ------------------------------------------------
+// `vec` = both arrays are 16-byte aligned (chunk bases are even, so pairs are aligned too).
+__global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v, const double *__restrict__ w,
+                                                   long count, long nchunks, int vec, double *__restrict__ approx)
+{
+    const int lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const long base = c * kChunk;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPerLane / 2; ++k) {
+        double p0, p1;
+        product_pair(v, w, base + k * 128 + 2 * lane, count, vec != 0, p0, p1);
+        acc += p0;
+        acc += p1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) approx[c] = acc;
+}
+
+// Sum of each group's 64 chunk sums.
+__global__ __launch_bounds__(256) void k_xs_gsum(const double *__restrict__ approx, long nchunks,
+                                                 double *__restrict__ gsum, long ngroups)
+{
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const long i = g * kGroup + lane;
+    double acc = (i < nchunks) ? approx[i] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) gsum[g] = acc;
+}
+
+// In-place exclusive scan of the group sums, seeded with `start`.  One workgroup.
+__global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, long ngroups, double start)
+{
+    __shared__ double wave_tot[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long per = (ngroups + 1023) / 1024;
+    const long lo = (long)t * per, hi = (lo + per < ngroups) ? lo + per : ngroups;
+    double mine = 0.0;
+    for (long g = lo; g < hi; ++g) mine += gsum[g];
+    double inc = mine;                               // inclusive scan inside the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += up;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    double before = start;
+    for (int k = 0; k < wv; ++k) before += wave_tot[k];
+    double run = before + (inc - mine);
+    for (long g = lo; g < hi; ++g) {
+        const double x = gsum[g];
+        gsum[g] = run;
+        run += x;
+    }
+}
+
+// ---- B: per-chunk integer summaries under the guessed exponent --------------------
+__global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, const double *__restrict__ w,
+                                                  long count, long nchunks, int vec, const double *__restrict__ approx,
+                                                  const double *__restrict__ goff, Summary *__restrict__ out)
+{
+    // Products are fetched coalesced (lane-interleaved) and handed to the lanes as 16
+    // CONSECUTIVE elements each through LDS; 18-double rows keep the 16-byte reads of the
+    // 16 lanes of a group on distinct banks.
+    __shared__ __attribute__((aligned(16))) double tile[4][64 * 18];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * 4 + wv;
+    if (c >= nchunks) return;                       // whole wavefront leaves together
+    const long base = c * kChunk;
+    double *T = tile[wv];
+#pragma unroll
+    for (int k = 0; k < kPerLane / 2; ++k) {
+        const int pos = k * 128 + 2 * lane;
+        double p0, p1;
+        product_pair(v, w, base + pos, count, vec != 0, p0, p1);
+        double *dst = T + (pos >> 4) * 18 + (pos & 15);
+        dst[0] = p0; dst[1] = p1;
+    }
+    // Guess of the accumulator at the chunk's start: scanned group offset + the chunk sums
+    // that precede this chunk inside its group.
+    const long gfirst = c & ~(long)(kGroup - 1);
+    double before = (gfirst + lane < c) ? approx[gfirst + lane] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    const int e = exponent_of(goff[c >> 6] + before);
+
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double p[kPerLane];
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) p[i] = T[lane * 18 + i];
+
+    const Summary s = wave_compose(piece_summary(p, e));
+    if (lane == 0) out[c] = s;
+}
+
+// ---- C: groups of 64 chunk summaries -------------------------------------------------
 __global__ __launch_bounds__(256) void k_xs_group(const Summary *__restrict__ in, long nin, Summary *__restrict__ out,
                                                   long nout)
 {
@@ -213,13 +260,13 @@ __global__ __launch_bounds__(256) void k_xs_group(const Summary *__restrict__ in
     if (lane == 0) out[g] = s;
 }
 
-// ---- E: the ordered walk ----------------------------------------------------------------
+// ---- D: the ordered walk ----------------------------------------------------------------
 
-// Does the hypothesis behind `c` hold for an accumulator S (in ulps, |S| in [2^52, 2^53))?
-__device__ __forceinline__ bool holds(const Summary &c, int es, double S)
+// Does the hypothesis behind `c` hold for the accumulator s = S * 2^(es-52)?
+__device__ __forceinline__ bool holds(const Summary &c, int es, double S, bool neg_zero)
 {
     if (c.bad) return false;
-    if (c.e == kAnyExp) return true;                // zeros only
+    if (c.e == kAnyExp) return !neg_zero;           // zeros only: s + 0 = s, except (-0) + (+0) = +0
     if (es == kNoExp || c.e != es) return false;
     if (S > 0.0) return (S + c.mn >= 0x1p52 + 1.0) && (S + c.mx <= 0x1p53 - 1.0);
     return (S + c.mx <= -(0x1p52 + 1.0)) && (S + c.mn >= -(0x1p53 - 1.0));
@@ -244,22 +291,24 @@ __device__ __forceinline__ double replay(const double *v, const double *w, long 
 }
 
 // Walk up to 64 summaries held one per lane (`mine`; lanes >= n hold nothing), in order,
-// starting from accumulator s.  Returns the index of the first summary that could not be
-// applied (n if all were) and updates s to the accumulator just before it.
+// starting at index `from` from accumulator s.  Returns the index of the first summary
+// that could not be applied (n if all were) and leaves s as the accumulator just before it.
 __device__ __forceinline__ int walk(Summary mine, int n, int from, double &s, int lane)
 {
     const int es = exponent_of(s);
     const double S = (es == kNoExp) ? 0.0 : ldexp(s, 52 - es);
+    const bool neg_zero = (s == 0.0) && signbit(s);
     Summary cur = (lane >= from && lane < n) ? mine : identity();
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {        // inclusive ordered scan
         const Summary prev = shfl_up(cur, off);
         if (lane >= off) cur = compose(prev, cur);
     }
-    const bool ok = holds(cur, es, S);
+    const bool ok = holds(cur, es, S, neg_zero);
     // validity is monotone along the scan (flags accumulate, extremes only widen)
-    unsigned long long okmask = __ballot(ok && lane >= from && lane < n);
-    unsigned long long want = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) & ~((from >= 64) ? ~0ull : ((1ull << from) - 1ull));
+    const unsigned long long okmask = __ballot(ok);
+    const unsigned long long upto = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    const unsigned long long want = upto & ~((1ull << from) - 1ull);
     const unsigned long long failed = want & ~okmask;
     const int f = failed ? (int)__builtin_ctzll(failed) : n;
     if (f > from) {
@@ -268,6 +317,35 @@ __device__ __forceinline__ int walk(Summary mine, int n, int from, double &s, in
         if (ce != kAnyExp) s = ldexp(S + D, es - 52);   // exact: integers below 2^53
     }
     return f;
+}
+
+// A chunk whose stored summary does not apply: cut it into 64 pieces of 16 elements (one per
+// lane), summarise the pieces under the accumulator's ACTUAL exponent, apply the longest
+// valid run, replay the one offending piece literally, and repeat with the new exponent.
+__device__ __forceinline__ double refine(const double *v, const double *w, long lo, long hi, double s, int lane)
+{
+    double p[kPerLane];
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+        const long idx = lo + (long)lane * kPerLane + i;
+        p[i] = (idx < hi) ? v[idx] * w[idx] : 0.0;
+    }
+    int piece = 0;
+    for (int round = 0; piece < 64; ++round) {
+        if (round >= 8)                              // many ties or crossings: not worth summarising
+            return replay(v, w, lo + (long)piece * kPerLane, hi, s, lane);
+        const Summary mine = piece_summary(p, exponent_of(s));
+        const int f = walk(mine, 64, piece, s, lane);
+        if (f >= 64) break;
+        const long first = lo + (long)f * kPerLane;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const double pi = __shfl(p[i], f, 64);
+            if (first + i < hi) s += pi;
+        }
+        piece = f + 1;
+    }
+    return s;
 }
 
 __global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, const double *__restrict__ w, long count,
@@ -294,7 +372,7 @@ __global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, co
                 if (cf >= nc) break;
                 const long lo = (cb + cf) * kChunk;
                 const long hi = (lo + kChunk < count) ? lo + kChunk : count;
-                s = replay(v, w, lo, hi, s, lane);
+                s = refine(v, w, lo, hi, s, lane);
                 cpos = cf + 1;
             }
             gpos = gf + 1;
@@ -305,8 +383,7 @@ __global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, co
 
 // Workspace for `count` elements.
 struct Workspace {
-    double *approx = nullptr;
-    int *guess = nullptr;
+    double *approx = nullptr, *goff = nullptr;
     Summary *chunks = nullptr, *groups = nullptr;
     long cap_chunks = 0;
 
@@ -319,7 +396,7 @@ struct Workspace {
         const long ng = (nc + kGroup - 1) / kGroup;
         hipError_t e;
         if ((e = hipMalloc(&approx, (size_t)nc * sizeof(double))) != hipSuccess) return e;
-        if ((e = hipMalloc(&guess, (size_t)nc * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMalloc(&goff, (size_t)ng * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&chunks, (size_t)nc * sizeof(Summary))) != hipSuccess) return e;
         if ((e = hipMalloc(&groups, (size_t)ng * sizeof(Summary))) != hipSuccess) return e;
         cap_chunks = nc;
@@ -327,8 +404,8 @@ struct Workspace {
     }
     void release()
     {
-        (void)hipFree(approx); (void)hipFree(guess); (void)hipFree(chunks); (void)hipFree(groups);
-        approx = nullptr; guess = nullptr; chunks = nullptr; groups = nullptr; cap_chunks = 0;
+        (void)hipFree(approx); (void)hipFree(goff); (void)hipFree(chunks); (void)hipFree(groups);
+        approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; cap_chunks = 0;
     }
 };
 
@@ -337,12 +414,18 @@ struct Workspace {
 inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
                     double *result)
 {
+    if (count <= 0) {
+        hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, 0L, ws.chunks, 0L, ws.groups, 0L, start, result);
+        return;
+    }
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
     const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4);
-    hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, ws.approx);
-    hipLaunchKernelGGL(k_xs_guess, dim3(1), dim3(1024), 0, s, ws.approx, nc, start, ws.guess);
-    hipLaunchKernelGGL(k_xs_chunk, dim3(cb), dim3(256), 0, s, v, w, count, nc, ws.guess, ws.chunks);
+    const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
+    hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
+    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start);
+    hipLaunchKernelGGL(k_xs_chunk, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
     hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, start, result);
 }

@@ -229,7 +229,7 @@ struct cg_ctx {
     int effective_schedule() const
     {
         if (schedule >= 0) return schedule;
-        return reduce == CG_REDUCE_STRICT ? CG_SCHED_CLASSIC : CG_SCHED_FUSED_NOQ;
+        return reduce == CG_REDUCE_STRICT ? CG_SCHED_FUSED : CG_SCHED_FUSED_NOQ;   // strict order needs q stored
     }
     bool has_top() const { return row0 > 0; }
     bool has_bot() const { return row0 + rows < G; }
@@ -766,8 +766,8 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     if (max_iters < 0 || rtol < 0) return fail(CG_ERR_ARG, "cg_solve: max_iters and rtol must be >= 0");
     CGCHK(select_device(c->device));
     const int sched = c->effective_schedule();
-    if (c->reduce == CG_REDUCE_STRICT && sched != CG_SCHED_CLASSIC)
-        return fail(CG_ERR_STATE, "strict reduction order needs the CLASSIC schedule (q must be stored)");
+    if (c->reduce == CG_REDUCE_STRICT && sched == CG_SCHED_FUSED_NOQ)
+        return fail(CG_ERR_STATE, "strict reduction order needs a schedule that stores q (CLASSIC or FUSED)");
     if (c->nranks > 1 && !c->comm) return fail(CG_ERR_STATE, "multi-rank context without cg_comm_init");
     hipStream_t s = c->stream;
 

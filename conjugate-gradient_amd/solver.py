@@ -129,7 +129,7 @@ class CGSolver:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
             if schedule is None and reduce == _l.REDUCE_STRICT:
-                schedule = _l.SCHED_CLASSIC
+                schedule = _l.SCHED_FUSED
         if schedule is not None:
             self.set_option(_l.OPT_SCHEDULE, schedule)
             self.schedule = schedule

@@ -88,7 +88,7 @@ typedef struct cg_ctx cg_ctx;
 
 /* Option keys for cg_set_option. */
 #define CG_OPT_REDUCE      1   /* CG_REDUCE_*                        default FAST     */
-#define CG_OPT_SCHEDULE    2   /* CG_SCHED_*                         default FUSED_NOQ (CLASSIC when strict) */
+#define CG_OPT_SCHEDULE    2   /* CG_SCHED_*                         default FUSED_NOQ (FUSED when strict: q must be stored) */
 #define CG_OPT_TILE_H      3   /* rows per stencil tile, 0 = auto                     */
 #define CG_OPT_GRAPH_ITERS 4   /* iterations captured per hipGraph, 0 = no graph; default 10 */
 #define CG_OPT_XCD_REMAP   5   /* 1 = XCD-aware tile order (default), 0 = plain order  */

@@ -160,7 +160,7 @@ int main(int argc, char **argv)
         cg_ctx *ctx = NULL;
         CK(cg_create(&ctx, device, n, row0, rows, rank, numprocs), "cg_create");
         const char *se = getenv("CG_SCHEDULE");
-        int sched = strict ? CG_SCHED_CLASSIC : CG_SCHED_FUSED_NOQ;
+        int sched = strict ? CG_SCHED_FUSED : CG_SCHED_FUSED_NOQ;
         if (se && strcmp(se, "classic") == 0) sched = CG_SCHED_CLASSIC;
         else if (se && strcmp(se, "fused") == 0) sched = CG_SCHED_FUSED;
         else if (se && strcmp(se, "fused_noq") == 0) sched = CG_SCHED_FUSED_NOQ;
