@@ -185,6 +185,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double *row, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(row), 0, row != nullptr ? bytes : 0, kRsrcFlags);
 }
 
+// Same for a row pointer known to be valid (no null test, so no scalar branch).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc_nn(const double *row, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(row), 0, bytes, kRsrcFlags);
+}
+
 template <int VEC> struct BufIO;
 template <> struct BufIO<1> {
     static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int off, double (&v)[1])
@@ -234,7 +240,13 @@ struct RawRow {
 // MODE 0: q = A d, partials of d.q                      (stencil entry points)
 // MODE 1: d' = beta*d - g, q = A d', partials of d'.q   (fused d-update)
 // MODE 2: q = A d recomputed, u += tau*d, g += tau*q, partials of g.g
-template <int VEC, int MODE, bool WRITE_Q, int PF>
+//
+// CONTIG: the halo rows sit in memory directly above and below the block (row r of
+// every array is base + r*G for r = -1 .. rows; the solver context allocates its
+// vectors that way, with zero rows where there is no neighbour).  Row addresses are
+// then a pure linear function and the per-row scalar work shrinks to an add; the
+// general form (separate halo pointers, possibly null) serves the stand-alone entry.
+template <int VEC, int MODE, bool WRITE_Q, int PF, bool CONTIG>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 {
     constexpr bool FUSE_D = (MODE == 1);
@@ -285,13 +297,13 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     };
     auto load_row = [&](long r, RawRow<VEC> &raw) {
         const bool live = r <= r1;                    // rows past the tile's lower halo are not needed
-        const double *pd = row_ptr(a.d_in, a.d_top, a.d_bot, r);
-        const __amdgpu_buffer_rsrc_t rd = row_rsrc(pd, live ? rowbytes : 0);
+        const double *pd = CONTIG ? a.d_in + r * G : row_ptr(a.d_in, a.d_top, a.d_bot, r);
+        const __amdgpu_buffer_rsrc_t rd = CONTIG ? row_rsrc_nn(pd, live ? rowbytes : 0) : row_rsrc(pd, live ? rowbytes : 0);
         BufIO<VEC>::load(rd, off_main, raw.d);
         raw.ed = buf_load1(rd, off_edge);
         if (FUSE_D) {
-            const double *pg = row_ptr(a.g, a.g_top, a.g_bot, r);
-            const __amdgpu_buffer_rsrc_t rg = row_rsrc(pg, live ? rowbytes : 0);
+            const double *pg = CONTIG ? a.g + r * G : row_ptr(a.g, a.g_top, a.g_bot, r);
+            const __amdgpu_buffer_rsrc_t rg = CONTIG ? row_rsrc_nn(pg, live ? rowbytes : 0) : row_rsrc(pg, live ? rowbytes : 0);
             BufIO<VEC>::load(rg, off_main, raw.g);
             raw.eg = buf_load1(rg, off_edge);
         } else {
@@ -299,8 +311,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
         }
         if (MODE == 2) {
             const bool own = (r >= r0) && (r < r1);
-            BufIO<VEC>::load(row_rsrc(a.u + r * G, own ? rowbytes : 0), off_main, raw.u);
-            BufIO<VEC>::load(row_rsrc(a.gw + r * G, own ? rowbytes : 0), off_main, raw.g);
+            BufIO<VEC>::load(row_rsrc_nn(a.u +r * G, own ? rowbytes : 0), off_main, raw.u);
+            BufIO<VEC>::load(row_rsrc_nn(a.gw +r * G, own ? rowbytes : 0), off_main, raw.g);
         }
     };
 
@@ -329,9 +341,15 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 edge = beta * raw.ed - raw.eg;
                 // Owned rows go to d_out; a neighbour's boundary row (known here only as a
                 // halo) is kept up to date locally, so that only g has to travel.
-                const double *dst = (r >= r0 && r < r1) ? a.d_out + r * G
-                                  : ((r < 0) ? a.d_top_out : ((r >= a.rows && r <= r1) ? a.d_bot_out : nullptr));
-                BufIO<VEC>::store(row_rsrc(dst, rowbytes), off_main, cur);
+                if (CONTIG) {
+                    const bool wr = (r >= r0 && r < r1) || (r < 0 && a.d_top_out != nullptr) ||
+                                    (r >= a.rows && r <= r1 && a.d_bot_out != nullptr);
+                    BufIO<VEC>::store(row_rsrc_nn(a.d_out + r * G, wr ? rowbytes : 0), off_main, cur);
+                } else {
+                    const double *dst = (r >= r0 && r < r1) ? a.d_out + r * G
+                                      : ((r < 0) ? a.d_top_out : ((r >= a.rows && r <= r1) ? a.d_bot_out : nullptr));
+                    BufIO<VEC>::store(row_rsrc(dst, rowbytes), off_main, cur);
+                }
             } else {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) cur[v] = raw.d[v];
@@ -372,13 +390,13 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     pg[v] = mid_g[v] + tau * qv[v];
                     acc += pg[v] * pg[v];             // masked rows/lanes hold g = 0
                 }
-                BufIO<VEC>::store(row_rsrc(a.u + m * G, row_own ? rowbytes : 0), off_main, pu);
-                BufIO<VEC>::store(row_rsrc(a.gw + m * G, row_own ? rowbytes : 0), off_main, pg);
+                BufIO<VEC>::store(row_rsrc_nn(a.u +m * G, row_own ? rowbytes : 0), off_main, pu);
+                BufIO<VEC>::store(row_rsrc_nn(a.gw +m * G, row_own ? rowbytes : 0), off_main, pg);
             } else {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc += mid[v] * qv[v];   // q = 0 off the interior
                 if (WRITE_Q) {
-                    const __amdgpu_buffer_rsrc_t rq = row_rsrc(a.q + m * G, row_in ? rowbytes : 0);
+                    const __amdgpu_buffer_rsrc_t rq = row_rsrc_nn(a.q + m * G, row_in ? rowbytes : 0);
                     BufIO<VEC>::store(rq, off_qv, qv);
                     if (VEC == 2) {
                         buf_store1(rq, off_q0, qv[0]);
