@@ -123,6 +123,7 @@ struct StencilArgs {
     int rt_first;                     // first row tile of this launch
     int rt_total;                     // row tiles in the whole block
     int edge_pair;                    // 1 = this launch covers row tiles 0 and rt_total-1 only
+    long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
 };
 
 // Streaming accesses carry the non-temporal hint (global_load/store ... nt): every
@@ -257,8 +258,10 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     __shared__ double wave_slots[kWaves];
 
     const int tid = threadIdx.x;
-    const long ntiles = (long)gridDim.x;
-    const long lt = a.remap ? xcd_remap(blockIdx.x, ntiles) : (long)blockIdx.x;
+    const long nwg = (long)gridDim.x;
+    // A launch may have fewer workgroups than tiles: workgroup b then walks tiles
+    // b', b' + nwg, b' + 2 nwg, ... one after the other (b' = its XCD-aware slot).
+    for (long lt = a.remap ? xcd_remap(blockIdx.x, nwg) : (long)blockIdx.x; lt < a.ntiles_launch; lt += nwg) {
     const long strip = lt % a.nstrips, lrt = lt / a.nstrips;
     const long rt = a.edge_pair ? (lrt == 0 ? 0 : a.rt_total - 1) : a.rt_first + lrt;
     const long tile = rt * a.nstrips + strip;         // index in the whole block: fixes the partial's slot
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 
     const double s = block_sum(acc, wave_slots);
     if (tid == 0) a.partials[tile] = s;
+    }
 }
 
 // ------------------------------------------------------------- flat kernels --

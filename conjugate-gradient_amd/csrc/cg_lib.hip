@@ -126,6 +126,7 @@ struct TileGeom {
     int nstrips;
     int tile_h;
     long ntiles;
+    long max_wgs = 0; // > 0: at most this many workgroups per launch, each walking several tiles
 };
 
 TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
@@ -136,16 +137,21 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
     t.nstrips = (int)((G + W - 1) / W);
     long h = tile_h_opt;
     if (h <= 0) {
-        // One workgroup per CU (256 tiles of equal height): measured on MI355X, mixed
-        // read/write streams reach their best HBM efficiency with few, long-lived
-        // workgroups that each keep several rows of loads in flight (5.3-5.6 TB/s at
-        // 256 tiles against 5.0-5.2 at 1024+), and tall tiles make the two halo rows a
-        // tile re-reads negligible.  Heights that leave a short last tile lose to
-        // imbalance, so round the tile count per strip, not the height.
+        // One workgroup per CU (256 of them): measured on MI355X, mixed read/write
+        // streams reach their best HBM efficiency with few, long-lived workgroups that
+        // each keep several rows of loads in flight (5.3-5.6 TB/s at 256 workgroups
+        // against 5.0-5.2 at 1024+).  Each workgroup walks tiles of about 512 rows and
+        // then jumps ahead to its next tile, which keeps the 256 of them within a narrower
+        // window of memory than one tall tile each would (1-2 % faster at 16384^2); the
+        // two halo rows a tile re-reads stay negligible.  Heights that leave a short last
+        // tile lose to imbalance, so round the tile count per strip, not the height.
         long per_strip = 256 / t.nstrips;
         if (per_strip < 1) per_strip = 1;
-        h = (rows + per_strip - 1) / per_strip;
+        const long tall = (rows + per_strip - 1) / per_strip;      // one tile per workgroup
+        const long rounds = tall >= 768 ? (tall + 256) / 512 : 1;  // tiles each workgroup walks
+        h = (rows + per_strip * rounds - 1) / (per_strip * rounds);
         if (h < 16) h = 16;
+        t.max_wgs = (long)t.nstrips * per_strip;
     }
     if (h > rows) h = rows;
     if (h < 1) h = 1;
@@ -157,11 +163,14 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
 // Launches the row tiles the arguments select: all of them (rt_first = 0), a
 // contiguous run starting at rt_first, or the first and last one (edge_pair).
 template <int MODE, bool WRITE_Q>
-void launch_stencil(const TileGeom &t, const StencilArgs &a, hipStream_t s, long row_tiles = -1)
+void launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, long row_tiles = -1)
 {
     const long nrt = row_tiles >= 0 ? row_tiles : t.ntiles / t.nstrips;
     if (nrt <= 0) return;
-    const dim3 grid((unsigned)(nrt * t.nstrips)), block(kBlock);
+    StencilArgs a = a0;
+    a.ntiles_launch = nrt * t.nstrips;
+    const long nwg = (t.max_wgs > 0 && t.max_wgs < a.ntiles_launch) ? t.max_wgs : a.ntiles_launch;
+    const dim3 grid((unsigned)nwg), block(kBlock);
 #define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C>), grid, block, 0, s, a)
     if (!t.contig) {                  // stand-alone entry point: caller-supplied halo pointers
         if (t.vec == 2) CG_LAUNCH(2, 4, false);
@@ -198,6 +207,7 @@ struct cg_ctx {
     int remap = 1;
     long flat_blocks_opt = 0;
     int prefetch = 4;
+    long tile_wgs = 0;
     bool graph_explicit = false;          // the caller set CG_OPT_GRAPH_ITERS
 
     // device state
@@ -247,6 +257,7 @@ TileGeom ctx_geom(const cg_ctx *c)
 {
     TileGeom t = tile_geom(c->G, c->rows, true, c->tile_h);
     t.pf = c->prefetch;
+    if (c->tile_wgs > 0) t.max_wgs = c->tile_wgs;
     t.contig = 1;
     return t;
 }
@@ -748,6 +759,9 @@ int cg_set_option(cg_ctx *c, int key, long value)
     case CG_OPT_PREFETCH:
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(CG_ERR_ARG, "prefetch depth must be 1, 2, 4 or 8");
         c->prefetch = (int)value; break;
+    case CG_OPT_TILE_WGS:
+        if (value < 0) return fail(CG_ERR_ARG, "workgroup cap must be >= 0");
+        c->tile_wgs = value; break;
     case CG_OPT_STRICT_IMPL:
         if (value < kStrictAuto || value > kStrictParallel) return fail(CG_ERR_ARG, "strict implementation must be 1, 2 or 3");
         c->strict_impl = (int)value; break;

@@ -16,6 +16,7 @@ REDUCE_FAST, REDUCE_STRICT = 0, 1
 SCHED_CLASSIC, SCHED_FUSED, SCHED_FUSED_NOQ = 0, 1, 2
 OPT_REDUCE, OPT_SCHEDULE, OPT_TILE_H, OPT_GRAPH_ITERS, OPT_XCD_REMAP, OPT_FLAT_BLOCKS, OPT_PREFETCH = 1, 2, 3, 4, 5, 6, 7
 OPT_STRICT_IMPL = 8
+OPT_TILE_WGS = 9
 STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL = 1, 2, 3
 VEC_U, VEC_G, VEC_D, VEC_Q = 0, 1, 2, 3
 

@@ -96,6 +96,9 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_PREFETCH    7   /* rows of loads each thread keeps in flight: 1, 2, 4 (default) or 8 */
 #define CG_OPT_STRICT_IMPL 8   /* how the strict order is evaluated: 1 = auto (default), 2 = literal
                                   one-accumulator replay, 3 = parallel evaluation (same bits, see cg_dot) */
+#define CG_OPT_TILE_WGS    9   /* cap on workgroups per tiled launch; with more tiles than that each
+                                  workgroup walks several tiles in turn.  0 = auto (256 with automatic
+                                  tile height, one workgroup per tile with an explicit CG_OPT_TILE_H) */
 
 /* A context owns the row block [row0, row0+rows) x (n+1) of u, g, d, q on
  * `device`.  Single GPU: row0 = 0, rows = n+1, rank 0 of 1.                  */

@@ -295,7 +295,8 @@ def test_headline_16384_1000_against_reference_golden(cg, golden):
     # sum moves q1 by ~2e-7 (measured 2.2e-7).  The strict order is the bit-exact path at this size.
     assert abs(r.q1 - q1_ref) <= 1e-6 * q1_ref
     u = s.vector(cg.VEC_U)
-    assert abs(float(np.sum(u)) - float(rec["sum_u"])) <= FAST_U_RTOL * float(rec["sum_u"])
+    # sum(u) moves by 0.5e-8 .. 1.3e-8 (relative) between launch geometries of the fast order alone
+    assert abs(float(np.sum(u)) - float(rec["sum_u"])) <= 1e-7 * float(rec["sum_u"])
     x = np.arange(16384) / 16383
     err = np.max(np.abs(u - np.outer(x * (1 - x), x * (1 - x))))
     assert abs(err - float(rec["max_err"])) <= 1e-6 * float(rec["max_err"])

@@ -69,13 +69,24 @@ template <int VAR, int PF> void run(const char *tag, double *a, double *b, doubl
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 8;
     printf("%-34s pf=%d blocks=%4d : %7.3f ms %6.0f GB/s\n", tag, PF, nstrips * nbands, ms, 3.0 * G * G * 8 / 1e9 / (ms * 1e-3)); fflush(stdout);
 }
-int main()
+__global__ void k_fill(double *p, size_t n, unsigned seed)
 {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + seed) * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;      // random mantissa bits
+    }
+}
+int main(int argc, char **argv)
+{
+    const bool rnd = argc > 1 && argv[1][0] == 'r';      // "rand": random operand bits instead of zeros
     const long G = 16384; const size_t bytes = (size_t)G * G * 8;
     double *a, *b, *c; CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes)); CHECK(hipMalloc(&c, bytes));
     CHECK(hipMemset(a, 0, bytes)); CHECK(hipMemset(b, 0, bytes)); CHECK(hipMemset(c, 0, bytes));
-    for (int nb : {8, 16, 32}) {
+    if (rnd) { k_fill<<<4096, 256>>>(a, bytes / 8, 1u); k_fill<<<4096, 256>>>(b, bytes / 8, 77u); CHECK(hipDeviceSynchronize()); }
+    printf("operands: %s\n", rnd ? "random" : "zeros");
+    for (int nb : {8}) {
         run<0, 1>("A batch load/store", a, b, c, G, nb); run<0, 2>("A batch load/store", a, b, c, G, nb); run<0, 4>("A batch load/store", a, b, c, G, nb);
+        run<0, 8>("A batch load/store", a, b, c, G, nb); run<0, 16>("A batch load/store", a, b, c, G, nb); run<0, 32>("A batch load/store", a, b, c, G, nb);
         run<1, 1>("B pipelined", a, b, c, G, nb); run<1, 2>("B pipelined", a, b, c, G, nb); run<1, 4>("B pipelined", a, b, c, G, nb);
         run<2, 1>("C pipelined+LDS+barrier", a, b, c, G, nb); run<2, 2>("C pipelined+LDS+barrier", a, b, c, G, nb); run<2, 4>("C pipelined+LDS+barrier", a, b, c, G, nb);
         run<3, 1>("D = C with buffer ops", a, b, c, G, nb); run<3, 2>("D = C with buffer ops", a, b, c, G, nb); run<3, 4>("D = C with buffer ops", a, b, c, G, nb);

@@ -8,13 +8,14 @@ tiles = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 
 scheds = {"noq": cg.SCHED_FUSED_NOQ, "classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED}
 which_s = sys.argv[3].split(",") if len(sys.argv) > 3 else ["noq"]
 pfs = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [4]
+wgs = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
 s = cg.CGSolver(n)
 for name in which_s:
     sched = scheds[name]
     for pf in pfs:
-        for th in tiles:
-            s.configure(schedule=sched, tile_h=th, xcd_remap=1, prefetch=pf).init_problem()
-            line = f"pf={pf} {name:8s} tile_h={th:5d}"
+        for th, wg in itertools.product(tiles, wgs):
+            s.configure(schedule=sched, tile_h=th, xcd_remap=1, prefetch=pf, tile_wgs=wg).init_problem()
+            line = f"pf={pf} {name:8s} tile_h={th:5d} wgs={wg:4d}"
             tot = 0.0
             for which in (0, 1):
                 ms, nb = s.time_kernel(which, reps=10)
