@@ -190,6 +190,17 @@ class CGSolver:
         _l.check(self._lib.cg_copy_out(self._ctx, which, out.ctypes.data_as(C.c_void_p), self.count))
         return out.reshape(self.rows, self.G)
 
+    def vector_rows(self, which, row, nrows):
+        """Rows [row, row+nrows) of one of the context's vectors (local row index), without copying the rest."""
+        if row < 0 or nrows < 0 or row + nrows > self.rows:
+            raise ValueError("row range outside the block")
+        p = C.c_void_p()
+        _l.check(self._lib.cg_device_ptr(self._ctx, which, C.byref(p)))
+        out = np.empty(nrows * self.G, dtype=np.float64)
+        _l.check(self._lib.cg_copy_to_host(self.device, out.ctypes.data_as(C.c_void_p),
+                                           C.c_void_p(p.value + 8 * row * self.G), out.size))
+        return out.reshape(nrows, self.G)
+
     def history(self, count):
         out = np.empty(max(int(count), 1), dtype=np.float64)
         n = C.c_long(0)

@@ -94,3 +94,20 @@ def test_history_and_stop_semantics(oracle):
     assert r["hist"][-1] <= thr
     assert np.all(r["hist"][:-1] > thr)
     assert len(r["hist"]) == r["iters"]
+
+
+@pytest.mark.parametrize("n,chunk", [(63, 16), (255, 64), (1023, 128)])
+def test_chunked_first_iteration_equals_whole_grid_oracle(oracle, n, chunk):
+    # the row-chunked evaluation used to check grids that do not fit host memory
+    from chunked_oracle import first_iteration
+    ref = oracle.cg(n, 1)
+    G = n + 1
+    sample = [0, 1, chunk - 1, chunk, G // 2, G - 2, G - 1]
+    got = first_iteration(oracle, n, chunk, sample, workers=4)
+    assert float(got["q0"]).hex() == float(ref["q_init"]).hex()
+    assert float(got["q1"]).hex() == float(ref["q1"]).hex()
+    for i in sample:
+        u1, g1, d1 = got["rows"][i]
+        assert np.array_equal(u1.view(np.uint64), ref["u"][i].view(np.uint64))
+        assert np.array_equal(g1.view(np.uint64), ref["g"][i].view(np.uint64))
+        assert np.array_equal(d1.view(np.uint64), ref["d"][i].view(np.uint64))
