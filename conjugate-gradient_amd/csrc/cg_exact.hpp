@@ -179,9 +179,12 @@ __global__ __launch_bounds__(256) void k_xs_gsum(const double *__restrict__ appr
     if (lane == 0) gsum[g] = acc;
 }
 
-// In-place exclusive scan of the group sums, seeded with `start`.  One workgroup.
-__global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, long ngroups, double start)
+// In-place exclusive scan of the group sums, seeded with `start` (or, when `start_dev` is
+// given, with the device-resident value it points to).  One workgroup.
+__global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, long ngroups, double start,
+                                                   const double *start_dev)
 {
+    if (start_dev != nullptr) start = *start_dev;
     __shared__ double wave_tot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const long per = (ngroups + 1023) / 1024;
@@ -351,10 +354,10 @@ __device__ __forceinline__ double refine(const double *v, const double *w, long 
 __global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, const double *__restrict__ w, long count,
                                                 const Summary *__restrict__ chunks, long nchunks,
                                                 const Summary *__restrict__ groups, long ngroups, double start,
-                                                double *__restrict__ result)
+                                                const double *start_dev, double *result)
 {
     const int lane = threadIdx.x;
-    double s = start;
+    double s = (start_dev != nullptr) ? *start_dev : start;
     for (long gb = 0; gb < ngroups; gb += 64) {
         const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
         const Summary gmine = (lane < ng) ? groups[gb + lane] : identity();
@@ -409,13 +412,16 @@ struct Workspace {
     }
 };
 
-// result <- the reference's sequential dot product of v and w started from `start`.
+// result <- the reference's sequential dot product of v and w started from `start`, or from
+// *start_dev (read on the device when the kernels run: a value an earlier kernel or a
+// neighbouring rank produced) when start_dev is not null.  `result` may alias `start_dev`.
 // Stream-ordered; the workspace must have been reserved for `count`.
 inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
-                    double *result)
+                    double *result, const double *start_dev = nullptr)
 {
     if (count <= 0) {
-        hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, 0L, ws.chunks, 0L, ws.groups, 0L, start, result);
+        hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, 0L, ws.chunks, 0L, ws.groups, 0L, start,
+                           start_dev, result);
         return;
     }
     const long nc = Workspace::chunks_for(count);
@@ -424,10 +430,11 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
     const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;
     hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
     hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
-    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start);
+    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, start_dev);
     hipLaunchKernelGGL(k_xs_chunk, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
-    hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, start, result);
+    hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, start,
+                       start_dev, result);
 }
 
 } // namespace exact

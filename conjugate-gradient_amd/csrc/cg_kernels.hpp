@@ -524,10 +524,10 @@ __global__ __launch_bounds__(kBlock) void k_dot_partial(const double *__restrict
 // CPU loop; the price is one dependent fp64 add per element.
 __global__ __launch_bounds__(64) void k_dot_strict(const double *__restrict__ v,
                                                    const double *__restrict__ w, long count,
-                                                   double start, double *result)
+                                                   double start, const double *start_dev, double *result)
 {
     const int lane = threadIdx.x;
-    double acc = start;
+    double acc = (start_dev != nullptr) ? *start_dev : start;     // device-resident seed: chained ranks
     long base = 0;
     for (; base + 64 <= count; base += 64) {
         const double p = v[base + lane] * w[base + lane];

@@ -288,12 +288,22 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
     hipStream_t s = c->stream;
     const double *src = nullptr;
     if (c->reduce == CG_REDUCE_STRICT) {
-        if (c->nranks > 1) return fail(CG_ERR_STATE, "strict reduction order is single-GPU only");
-        if (use_parallel_strict(c->strict_impl, c->count))
-            cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, c->strict_slot);     // workspace reserved by cg_solve
-        else
-            hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, c->strict_slot);
-        src = c->strict_slot;
+        // One accumulator over the whole grid in index order.  Row blocks are contiguous
+        // in that order, so with several ranks the accumulator is handed from rank to rank:
+        // in round k rank k continues from rank k-1's value, and an all-gather of one double
+        // per rank publishes it.  The ranks take turns (this is the parity mode, not the
+        // fast one); every rank ends with the same bits a single rank would compute.
+        const bool par = use_parallel_strict(c->strict_impl, c->count);
+        for (int k = 0; k < c->nranks; ++k) {
+            double *slot = c->nranks > 1 ? c->comm->gather_buf() + c->rank : c->strict_slot;
+            const double *seed = k > 0 ? c->comm->gather_buf() + (k - 1) : nullptr;
+            if (k == c->rank) {
+                if (par) cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, slot, seed);   // workspace reserved by cg_solve
+                else hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, seed, slot);
+            }
+            if (c->nranks > 1) CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+        }
+        src = c->nranks > 1 ? c->comm->gather_buf() + (c->nranks - 1) : c->strict_slot;
     } else if (c->nranks > 1) {
         // local fixed-order sum -> all ranks' sums (RCCL all-gather) -> rank-order sum
         double *mine = c->comm->gather_buf() + c->rank;
@@ -595,7 +605,7 @@ int cg_dot(int device, long count, const double *v, const double *w, int strict,
             HIPCHK(sc->xs.reserve(count));
             cg::exact::enqueue(sc->stream, sc->xs, v, w, count, start, sc->slot);
         } else {
-            hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, sc->stream, v, w, count, start, sc->slot);
+            hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, sc->stream, v, w, count, start, nullptr, sc->slot);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(result_host, sc->slot, sizeof(double), hipMemcpyDeviceToHost, sc->stream));

@@ -80,7 +80,9 @@ typedef struct cg_ctx cg_ctx;
 
 /* Reduction order of the dot products. */
 #define CG_REDUCE_FAST    0    /* wavefront shuffle -> workgroup -> fixed-order grid sum */
-#define CG_REDUCE_STRICT  1    /* one accumulator, index order: bit-identical to the reference */
+#define CG_REDUCE_STRICT  1    /* one accumulator, index order: bit-identical to the reference on one
+                                  rank (utils.c:372-379); with several ranks the accumulator is handed
+                                  from rank to rank, so P row blocks still give the single-rank bits */
 /* Kernel schedule of one iteration (all produce bit-identical vectors). */
 #define CG_SCHED_CLASSIC  0    /* stencil+d.q | u,g update+g.g | d update        : 88 B/point */
 #define CG_SCHED_FUSED    1    /* d update fused into the stencil kernel         : 80 B/point */

@@ -1,6 +1,6 @@
 """One rank of a multi-process row-block solve (started by test_dist_gloo.py / test_gpu_multirank.py).
 
-  python dist_worker.py <mode> <n> <iters> <outdir> [schedule] [rtol]
+  python dist_worker.py <mode> <n> <iters> <outdir> [schedule] [rtol] [strict|strict_replay|strict_parallel]
 
 mode "oracle": the compute is the CPU oracle (checker code), the communication is the product's
                RowTransport over gloo -- this pins the transport's semantics without a GPU.
@@ -57,11 +57,15 @@ def oracle_rank(tr, dist_mod, n, iters, order):
     return dict(u=u, g=g, d=d, hist=np.array(hist), row0=row0)
 
 
-def gpu_rank(tr, cg, n, iters, schedule, rtol):
+def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast"):
     G = n + 1
     row0, rows = cg.dist.partition(G, tr.world, tr.rank)
     s = cg.CGSolver(n, device=0, row0=row0, rows=rows, rank=tr.rank, nranks=tr.world)
     s.configure(schedule={"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[schedule])
+    if order != "fast":                           # one accumulator handed from rank to rank
+        s.configure(reduce=cg.REDUCE_STRICT, schedule=s.schedule,
+                    strict_impl={"strict": cg.STRICT_AUTO, "strict_replay": cg.STRICT_REPLAY,
+                                 "strict_parallel": cg.STRICT_PARALLEL}[order])
     s.comm_init_host(tr)
     s.init_problem()
     if rtol > 0:
@@ -90,7 +94,8 @@ def main():
     if mode == "oracle":
         res = oracle_rank(tr, cg.dist, n, iters, extra[0] if extra else "chained")
     else:
-        res = gpu_rank(tr, cg, n, iters, extra[0] if extra else "fused_noq", float(extra[1]) if len(extra) > 1 else 0.0)
+        res = gpu_rank(tr, cg, n, iters, extra[0] if extra else "fused_noq", float(extra[1]) if len(extra) > 1 else 0.0,
+                       extra[2] if len(extra) > 2 else "fast")
     np.savez(os.path.join(outdir, f"rank{tr.rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
