@@ -98,9 +98,14 @@ def main():
     ap.add_argument("--n", type=int, default=16383, help="argv n of the reference: grid side is n+1")
     ap.add_argument("--schedule", choices=["classic", "fused", "fused_noq"], default="fused_noq")
     ap.add_argument("--tile-h", type=int, default=0)
-    ap.add_argument("--graph-iters", type=int, default=10)
+    ap.add_argument("--graph-iters", type=int, default=None,
+                    help="iterations per captured hipGraph (default: 10 on one GPU; eager launches with RCCL)")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="N > 1: RCCL inside the library, or host-staged rows over a gloo group (diagnostic)")
     ap.add_argument("--prefetch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0, gloo process group, host-staged transport")
     args = ap.parse_args()
 
     import torch
@@ -114,9 +119,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the CG hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank, args.transport = 0, "host"
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if args.share_gpu else "cuda"       # where the bench's own tiny collectives live
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n, G = args.n, args.n + 1
     if G % world:
@@ -125,10 +136,37 @@ def main():
     sched = {"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[args.schedule]
     s = cg.CGSolver(n, device=local_rank, row0=rank * rows, rows=rows, rank=rank, nranks=world)
     s.configure(reduce=cg.REDUCE_FAST, schedule=sched, tile_h=args.tile_h, graph_iters=args.graph_iters, prefetch=args.prefetch)
+    transport = "none"
     if world > 1:
-        ids = [cg.CGSolver.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        s.comm_init(ids[0])
+        transport, why = args.transport, ""
+        if transport == "rccl":
+            # The library opens its own RCCL communicator (id broadcast over the job's process group).
+            # If that fails on any rank, every rank falls back to host-staged rows: slower, but the
+            # run still measures the multi-rank solver instead of dying.
+            ok = 1
+            try:
+                ids = [cg.CGSolver.comm_unique_id() if rank == 0 else None]
+            except cg.CGError as e:
+                ids, ok, why = [None], 0, str(e)
+            dist.broadcast_object_list(ids, src=0)
+            if ids[0] is None:
+                ok = 0
+            else:
+                try:
+                    s.comm_init(ids[0])
+                except cg.CGError as e:
+                    ok, why = 0, str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                transport = "host"
+                if rank == 0:
+                    print(f"bench.py: RCCL transport unavailable ({why or 'failed on another rank'}); "
+                          f"using host-staged rows", file=sys.stderr, flush=True)
+        if transport == "host":
+            from importlib import import_module
+            cgdist = import_module("conjugate-gradient_amd.dist")
+            s.comm_init_host(cgdist.RowTransport(group=None if args.share_gpu else dist.new_group(backend="gloo")))
 
     def fence():
         torch.cuda.synchronize()
@@ -145,7 +183,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -161,14 +199,15 @@ def main():
             "config": {"workload": f"{G}x{G} fp64 grid, fixed-count CG, 5-point stencil "
                                    f"(BASELINE.json configs[{2 if world == 1 else 3}])",
                        "grid": G, "rows_per_gpu": rows, "schedule": args.schedule, "reduce": "fast",
-                       "bytes_per_point_per_iter": bpp, "graph_iters": args.graph_iters,
-                       "parallelism": f"rowblocks{world}"},
+                       "bytes_per_point_per_iter": bpp,
+                       "graph_iters": args.graph_iters if args.graph_iters is not None else (10 if world == 1 else 0),
+                       "transport": transport, "parallelism": f"rowblocks{world}"},
             "hbm_gbs_per_gpu": bpp * rows * G * its / 1e9,
             "hbm_frac_of_peak": bpp * rows * G * its / 1e9 / HBM_PEAK_GBS,
             "q1": res.q1, "iters_total": args.warmup + args.steps,
         }
-    # per-kernel roofline: HIP events on the solver's stream, this run, this GPU
-    if world == 1:
+    # per-kernel roofline: HIP events on the solver's stream, this run, this GPU (rank 0's row block)
+    if rank == 0:
         kern = {}
         for which, name in ((0, "stencil"), (1, "update")) + (((2, "dupdate"),) if sched == cg.SCHED_CLASSIC else ()):
             ms, nbytes = s.time_kernel(which, reps=20)
@@ -176,11 +215,13 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms"])
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
-                           "traffic": profiled_traffic(dom, G, args.schedule),
+                           "traffic": profiled_traffic(dom, G, args.schedule) if world == 1 else None,
                            "algorithmic_bytes_per_launch": kern[dom]["bytes"], "ms_per_launch": kern[dom]["ms"]}
         out["kernels"] = kern
-        s.close()
-        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n)
+        out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(n)
+    if world > 1:
+        dist.barrier()                       # no rank tears its communicator down while another still solves
+    s.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

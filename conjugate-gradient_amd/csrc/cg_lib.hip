@@ -945,8 +945,7 @@ int cg_get_history(cg_ctx *c, double *host_dst, long count, long *written)
 int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double *bytes_per_launch)
 {
     if (!c || !ms_per_launch || reps < 1) return fail(CG_ERR_ARG, "cg_time_kernel: bad arguments");
-    if (c->nranks > 1) return fail(CG_ERR_STATE, "cg_time_kernel is single-GPU only");
-    CGCHK(select_device(c->device));
+    CGCHK(select_device(c->device));                    // local kernels only: no communication, any rank may call it
     const int sched = c->effective_schedule();
     const TileGeom t = ctx_geom(c);
     hipStream_t s = c->stream;
