@@ -154,6 +154,7 @@ def main():
             else:
                 try:
                     s.comm_init(ids[0])
+                    s.comm_selftest()        # tagged all-gather + row exchange: wrong data is caught here, not in q1
                 except cg.CGError as e:
                     ok, why = 0, str(e)
             flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)

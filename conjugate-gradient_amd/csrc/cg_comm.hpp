@@ -43,6 +43,13 @@ public:
     virtual int exchange_rows(hipStream_t s, const double *base, long rows, long G, double *top_dst, double *bot_dst) = 0;
     // True if the calls above only enqueue stream work (hipGraph-capturable).
     virtual bool stream_ordered() const = 0;
+    // Self-test helper: move n doubles from src to dst through the transport's own
+    // point-to-point primitives addressed to this rank itself (a no-op copy where the
+    // transport has no such notion).  Lets a single process exercise send/receive.
+    virtual int loopback(hipStream_t s, const double *src, double *dst, long n)
+    {
+        return hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
+    }
 
 protected:
     bool alloc_gather(int nranks)
@@ -172,6 +179,15 @@ public:
             rc = check(api_->Send(base, (size_t)G, ncclDouble, rank_ - 1, comm_, s), "ncclSend(up)");
             if (rc == 0) rc = check(api_->Recv(top_dst, (size_t)G, ncclDouble, rank_ - 1, comm_, s), "ncclRecv(from above)");
         }
+        const int rc2 = check(api_->GroupEnd(), "ncclGroupEnd");
+        return rc != 0 ? rc : rc2;
+    }
+
+    int loopback(hipStream_t s, const double *src, double *dst, long n) override
+    {
+        int rc = check(api_->GroupStart(), "ncclGroupStart");
+        if (rc == 0) rc = check(api_->Send(src, (size_t)n, ncclDouble, rank_, comm_, s), "ncclSend(self)");
+        if (rc == 0) rc = check(api_->Recv(dst, (size_t)n, ncclDouble, rank_, comm_, s), "ncclRecv(self)");
         const int rc2 = check(api_->GroupEnd(), "ncclGroupEnd");
         return rc != 0 ? rc : rc2;
     }

@@ -215,6 +215,7 @@ struct cg_ctx {
     double *u = nullptr, *g = nullptr, *q = nullptr;
     double *g_alloc = nullptr, *d_alloc[2] = {nullptr, nullptr};   // g and d[] point one row into these
     double *u_alloc = nullptr, *q_alloc = nullptr;
+    size_t padded_bytes = 0;              // size of each of those allocations
     double *d[2] = {nullptr, nullptr};
     int dcur = 0;                         // which of d[] holds the current direction
     bool pending_dupdate = false;         // fused schedules: last d update not yet applied
@@ -695,6 +696,7 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
     const size_t padded = bytes + (size_t)(front + G) * sizeof(double);
     // (u and q get the same one-row offset: equal placement of all vectors relative to their
     // allocations measured ~10 % faster in the update kernel than mixed offsets)
+    c->padded_bytes = padded;
     alloc(&c->u_alloc, padded); alloc(&c->q_alloc, padded);
     alloc(&c->g_alloc, padded); alloc(&c->d_alloc[0], padded); alloc(&c->d_alloc[1], padded);
     alloc(&c->partials, 2 * (size_t)c->npart * sizeof(double));
@@ -1023,8 +1025,8 @@ int cg_comm_unique_id(void *id128)
 int cg_comm_init(cg_ctx *c, const void *id128)
 {
     if (!c || !id128) return fail(CG_ERR_ARG, "cg_comm_init: NULL argument");
-    if (c->nranks < 2) return fail(CG_ERR_STATE, "cg_comm_init on a single-rank context");
-    CGCHK(select_device(c->device));
+    CGCHK(select_device(c->device));                    // one rank is allowed: the solve ignores the communicator,
+                                                        // cg_comm_selftest can still exercise it
     delete c->comm;
     c->comm = nullptr;
     char msg[256];
@@ -1048,6 +1050,69 @@ int cg_comm_init_host(cg_ctx *c, cg_exchange_fn exchange, cg_allgather_fn allgat
     if (!comm) return fail(CG_ERR_COMM, "%s", msg);
     c->comm = comm;
     drop_graph(c);
+    return CG_OK;
+}
+
+// Transport check, collective over the ranks.  (1) every rank contributes 1000*(r+1)+0.5 to the
+// all-gather and must read back every other rank's value; (2) a row exchange on scratch rows
+// tagged with (rank, which end) must deliver the neighbours' tags; (3) one row is sent to this
+// rank itself.  Uses the second direction buffer as scratch: call it before cg_init_problem.
+int cg_comm_selftest(cg_ctx *c)
+{
+    if (!c) return fail(CG_ERR_ARG, "cg_comm_selftest: NULL context");
+    if (!c->comm) return fail(CG_ERR_STATE, "cg_comm_selftest: no communicator (cg_comm_init / cg_comm_init_host first)");
+    CGCHK(select_device(c->device));
+    hipStream_t s = c->stream;
+    const int P = c->nranks, r = c->rank;
+    const long G = c->G;
+    std::vector<double> vals((size_t)P, -1.0);
+    const double mine = 1000.0 * (r + 1) + 0.5;
+    HIPCHK(hipMemsetAsync(c->comm->gather_buf(), 0, (size_t)P * sizeof(double), s));
+    HIPCHK(hipMemcpyAsync(c->comm->gather_buf() + r, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+    HIPCHK(hipMemcpyAsync(vals.data(), c->comm->gather_buf(), (size_t)P * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int k = 0; k < P; ++k)
+        if (vals[(size_t)k] != 1000.0 * (k + 1) + 0.5)
+            return fail(CG_ERR_COMM, "all-gather self-test: slot %d holds %g on rank %d", k, vals[(size_t)k], r);
+
+    // rows: first row tagged 2r, last row tagged 2r+1 (one and the same row if the block has a single row)
+    double *blk = c->d[1];
+    std::vector<double> row((size_t)G);
+    auto fill = [&](double *dst, double tag) -> hipError_t {
+        for (long j = 0; j < G; ++j) row[(size_t)j] = tag + 1e-6 * (double)j;
+        return hipMemcpy(dst, row.data(), (size_t)G * sizeof(double), hipMemcpyHostToDevice);
+    };
+    if (c->rows >= 2) {
+        HIPCHK(fill(blk, 2.0 * r));
+        HIPCHK(fill(blk + (c->rows - 1) * G, 2.0 * r + 1.0));
+    } else {
+        HIPCHK(fill(blk, 2.0 * r));
+    }
+    CGCHK(comm_rc(c, c->comm->exchange_rows(s, blk, c->rows, G, c->halo_d[1][0], c->halo_d[1][1])));
+    HIPCHK(hipStreamSynchronize(s));
+    auto expect = [&](const double *src, double tag, const char *what) -> int {
+        if (hipMemcpy(row.data(), src, (size_t)G * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(CG_ERR_HIP, "row self-test: read-back failed");
+        for (long j = 0; j < G; ++j)
+            if (row[(size_t)j] != tag + 1e-6 * (double)j)
+                return fail(CG_ERR_COMM, "row self-test on rank %d: %s, column %ld holds %.9g, expected %.9g", r, what, j,
+                            row[(size_t)j], tag + 1e-6 * (double)j);
+        return CG_OK;
+    };
+    if (c->has_top()) CGCHK(expect(c->halo_d[1][0], 2.0 * (r - 1) + (c->rows >= 2 ? 1.0 : 0.0), "row from above"));   // equal blocks
+    if (c->has_bot()) CGCHK(expect(c->halo_d[1][1], 2.0 * (r + 1), "row from below"));
+
+    // loopback through the point-to-point primitives
+    HIPCHK(fill(blk, 77.0));
+    CGCHK(comm_rc(c, c->comm->loopback(s, blk, blk + G * (c->rows >= 2 ? 1 : 0), c->rows >= 2 ? G : 0)));
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->rows >= 2) CGCHK(expect(blk + G, 77.0, "loopback row"));
+
+    // leave the scratch rows as cg_create left them
+    HIPCHK(hipMemset(c->d_alloc[1], 0, c->padded_bytes));
+    HIPCHK(hipStreamSynchronize(nullptr));
     return CG_OK;
 }
 

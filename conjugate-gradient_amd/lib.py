@@ -64,6 +64,7 @@ SIGNATURES = {
     "cg_comm_unique_id": (C.c_int, [C.c_void_p]),
     "cg_comm_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cg_comm_init_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_comm_selftest": (C.c_int, [C.c_void_p]),
 }
 
 # callback prototypes of cg_comm_init_host (all pointers are host pointers)

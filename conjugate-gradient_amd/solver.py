@@ -175,6 +175,13 @@ class CGSolver:
         ex, ag = self._callbacks
         _l.check(self._lib.cg_comm_init_host(self._ctx, C.cast(ex, C.c_void_p), C.cast(ag, C.c_void_p), None))
 
+    def comm_selftest(self):
+        """Collective check of the transport (all-gather, row exchange, loopback); raises CGError on a mismatch.
+
+        Overwrites scratch vectors: call it before init_problem.
+        """
+        _l.check(self._lib.cg_comm_selftest(self._ctx))
+
     # -- solve -----------------------------------------------------------
     def init_problem(self):
         _l.check(self._lib.cg_init_problem(self._ctx))

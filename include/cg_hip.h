@@ -174,6 +174,15 @@ typedef int (*cg_exchange_fn)(void *user, const double *send_up, const double *s
 typedef int (*cg_allgather_fn)(void *user, double mine, double *all);
 int cg_comm_init_host(cg_ctx *ctx, cg_exchange_fn exchange, cg_allgather_fn allgather, void *user);
 
+/* Transport self-test, collective over the ranks of the communicator: an all-gather of one
+ * tagged double per rank, a tagged row exchange with the neighbours above and below, and one
+ * row sent to the calling rank itself; every received value is compared with what the sender
+ * must have sent.  Uses one of the direction buffers as scratch, so call it between
+ * cg_comm_init / cg_comm_init_host and cg_init_problem.  cg_comm_init also accepts a
+ * single-rank context so that one process can check the RCCL calls this way.
+ * (The reference has no counterpart: a failed MPI call in utils.c:221-274 simply aborts.) */
+int cg_comm_selftest(cg_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

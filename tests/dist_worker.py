@@ -67,6 +67,7 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast"):
                     strict_impl={"strict": cg.STRICT_AUTO, "strict_replay": cg.STRICT_REPLAY,
                                  "strict_parallel": cg.STRICT_PARALLEL}[order])
     s.comm_init_host(tr)
+    s.comm_selftest()                             # tagged all-gather and row exchange arrive where they should
     s.init_problem()
     if rtol > 0:
         r = s.solve(iters, rtol)

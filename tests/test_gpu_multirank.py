@@ -56,3 +56,14 @@ def test_multirank_strict_order_reproduces_single_rank_reference_bits(golden, or
     for k in ("u", "g", "d"):
         assert np.array_equal(stack(res, k).view(np.uint64), ref[k].view(np.uint64)), k
     assert np.array_equal(np.asarray(res[0]["hist"]).view(np.uint64), ref["hist"].view(np.uint64))
+
+
+def test_rccl_calls_on_a_single_rank_communicator(cg):
+    # One GPU cannot host two RCCL ranks, but a one-rank communicator still runs the library's
+    # dlopen of librccl, ncclCommInitRank, ncclAllGather and a grouped ncclSend/ncclRecv (to itself).
+    s = cg.CGSolver(255)
+    s.comm_init(cg.CGSolver.comm_unique_id())
+    s.comm_selftest()
+    r = s.init_problem().solve(20)                # the solve itself ignores a one-rank communicator
+    ref = cg.CGSolver(255).init_problem().solve(20)
+    assert float(r.q1).hex() == float(ref.q1).hex()
