@@ -51,6 +51,8 @@ struct Scalars {
     long long iter;     // iterations completed
     int done;           // set by k_finish when the stop rule fires
     int pad;
+    double tau_ring[8]; // tau of iteration i at [i & 7]: deferred u updates read them later
+    long long u_applied;// iterations whose tau*d has been added into u (lean schedule defers them)
 };
 
 // ---------------------------------------------------------------- reductions --
@@ -109,7 +111,8 @@ struct StencilArgs {
     double *d_out;                    // updated direction (fused d-update only)
     double *d_top_out, *d_bot_out;    // updated halo rows of d (fused d-update, multi-GPU only)
     double *q;                        // A d (may be nullptr when q is recomputed later)
-    double *u, *gw;                   // k_update_stencil: solution and gradient, updated in place
+    double *u, *gw;                   // MODE 2: solution and gradient, updated in place
+    double *g_out;                    // MODE 4: updated gradient (the other of two gradient buffers)
     double *partials;                 // one partial dot product per tile
     const Scalars *sc;
     long G;                           // grid side = row length
@@ -241,6 +244,12 @@ struct RawRow {
 // MODE 0: q = A d, partials of d.q                      (stencil entry points)
 // MODE 1: d' = beta*d - g, q = A d', partials of d'.q   (fused d-update)
 // MODE 2: q = A d recomputed, u += tau*d, g += tau*q, partials of g.g
+// MODE 3: MODE 1 without storing d' (reads only): partials of d'.q      (lean schedule, first pass)
+// MODE 4: d' = beta*d - g recomputed and stored, q = A d' recomputed, g' = g + tau*q stored to
+//         g_out, partials of g'.g'                                       (lean schedule, second pass)
+// MODE 5: MODE 4 plus the solution update of TWO iterations, u = (u + tau_prev*d) + tau*d':
+//         the previous iteration's direction d is this pass's input anyway and d' is in
+//         registers, so u costs one read and one write per two iterations
 //
 // CONTIG: the halo rows sit in memory directly above and below the block (row r of
 // every array is base + r*G for r = -1 .. rows; the solver context allocates its
@@ -250,7 +259,8 @@ struct RawRow {
 template <int VEC, int MODE, bool WRITE_Q, int PF, bool CONTIG>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 {
-    constexpr bool FUSE_D = (MODE == 1);
+    constexpr bool FUSE_D = (MODE == 1 || MODE >= 3);                // operands are d and g, d' is formed here
+    constexpr bool STORE_D = (MODE == 1 || MODE == 4 || MODE == 5);
     constexpr int W = kBlock * VEC;
     if (a.sc != nullptr && a.sc->done) return;
 
@@ -290,8 +300,10 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     }
 
     double beta = 0.0, tau = 0.0;
-    if (MODE == 1) beta = a.sc->beta;
-    if (MODE == 2) tau = a.sc->tau;
+    if (FUSE_D) beta = a.sc->beta;
+    double tau_prev = 0.0;
+    if (MODE == 2 || MODE == 4 || MODE == 5) tau = a.sc->tau;
+    if (MODE == 5) tau_prev = a.sc->tau_ring[(a.sc->iter - 1) & 7];   // iteration i-1's tau; this pass belongs to iteration i
 
     // Row r of the block, r in [-1, rows]; -1 and rows are the halo rows (nullptr at
     // the global boundary).  Everything here is wave-uniform scalar arithmetic.
@@ -312,16 +324,16 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
         } else {
             raw.eg = 0.0;
         }
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 5) {
             const bool own = (r >= r0) && (r < r1);
             BufIO<VEC>::load(row_rsrc_nn(a.u +r * G, own ? rowbytes : 0), off_main, raw.u);
-            BufIO<VEC>::load(row_rsrc_nn(a.gw +r * G, own ? rowbytes : 0), off_main, raw.g);
+            if (MODE == 2) BufIO<VEC>::load(row_rsrc_nn(a.gw +r * G, own ? rowbytes : 0), off_main, raw.g);
         }
     };
 
-    double up[VEC], mid[VEC], mid_u[VEC], mid_g[VEC], midL = 0.0, midR = 0.0;
+    double up[VEC], mid[VEC], mid_u[VEC], mid_g[VEC], mid_dp[VEC], midL = 0.0, midR = 0.0;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { up[v] = 0.0; mid[v] = 0.0; mid_u[v] = 0.0; mid_g[v] = 0.0; }
+    for (int v = 0; v < VEC; ++v) { up[v] = 0.0; mid[v] = 0.0; mid_u[v] = 0.0; mid_g[v] = 0.0; mid_dp[v] = 0.0; }
     double acc = 0.0;
 
     RawRow<VEC> ring[PF];
@@ -344,7 +356,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 edge = beta * raw.ed - raw.eg;
                 // Owned rows go to d_out; a neighbour's boundary row (known here only as a
                 // halo) is kept up to date locally, so that only g has to travel.
-                if (CONTIG) {
+                if (!STORE_D) {
+                } else if (CONTIG) {
                     const bool wr = (r >= r0 && r < r1) || (r < 0 && a.d_top_out != nullptr) ||
                                     (r >= a.rows && r <= r1 && a.d_bot_out != nullptr);
                     BufIO<VEC>::store(row_rsrc_nn(a.d_out + r * G, wr ? rowbytes : 0), off_main, cur);
@@ -395,6 +408,23 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 }
                 BufIO<VEC>::store(row_rsrc_nn(a.u +m * G, row_own ? rowbytes : 0), off_main, pu);
                 BufIO<VEC>::store(row_rsrc_nn(a.gw +m * G, row_own ? rowbytes : 0), off_main, pg);
+            } else if (MODE == 4 || MODE == 5) {
+                double pg[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    pg[v] = mid_g[v] + tau * qv[v];
+                    acc += row_own ? pg[v] * pg[v] : 0.0;   // halo rows carry g too here: not ours to count
+                }
+                BufIO<VEC>::store(row_rsrc_nn(a.g_out + m * G, row_own ? rowbytes : 0), off_main, pg);
+                if (MODE == 5) {
+                    double pu[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        pu[v] = mid_u[v] + tau_prev * mid_dp[v];     // cg.c:63-69 of the previous iteration
+                        pu[v] = pu[v] + tau * mid[v];                // ... and of this one
+                    }
+                    BufIO<VEC>::store(row_rsrc_nn(a.u + m * G, row_own ? rowbytes : 0), off_main, pu);
+                }
             } else {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc += mid[v] * qv[v];   // q = 0 off the interior
@@ -408,7 +438,9 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 }
             }
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) { up[v] = mid[v]; mid[v] = cur[v]; mid_u[v] = raw.u[v]; mid_g[v] = raw.g[v]; }
+            for (int v = 0; v < VEC; ++v) {
+                up[v] = mid[v]; mid[v] = cur[v]; mid_u[v] = raw.u[v]; mid_g[v] = raw.g[v]; mid_dp[v] = raw.d[v];
+            }
             midL = curL; midR = curR;
         }
     }
@@ -464,6 +496,60 @@ __global__ __launch_bounds__(kBlock) void k_dupdate(double *__restrict__ d, cons
         for (int v = 0; v < VEC; ++v) pd.v[v] = beta * pd.v[v] - pg.v[v];
         pd.store(d + k * VEC);
     }
+}
+
+// Left-over solution update of the lean schedule (a solve that ends between two paired
+// updates): u += tau_a*d_a, then + tau_b*d_b, in ascending iteration order -- the same
+// additions, in the same order, that cg.c:63-69 performs one iteration at a time.  Entry e is iteration sc->u_applied + e; the
+// host names the buffer that still holds that iteration's direction.  Only iterations that
+// really ran (index < sc->iter) are applied: launches queued behind a fired stop rule find
+// nothing to do.  k_umark, launched right after, advances sc->u_applied.
+struct UFlushArgs {
+    const double *d[2];               // direction of iteration sc->u_applied + e, e = 0 .. n-1
+    int n;
+};
+
+template <int VEC, int N>
+__device__ __forceinline__ void uflush_body(double *__restrict__ u, long count, const UFlushArgs &f, const double *tau)
+{
+    const long nvec = count / VEC;
+    const long stride = (long)gridDim.x * kBlock;
+    for (long k = (long)blockIdx.x * kBlock + threadIdx.x; k < nvec; k += stride) {
+        Pack<VEC> pu, pd[N];
+        pu.load(u + k * VEC);
+#pragma unroll
+        for (int e = 0; e < N; ++e) pd[e].load(f.d[e] + k * VEC);      // all N+1 loads in flight together
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) pu.v[v] = pu.v[v] + tau[e] * pd[e].v[v];
+        pu.store(u + k * VEC);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_uflush(double *__restrict__ u, long count, const UFlushArgs f,
+                                                   const Scalars *sc)
+{
+    const long long ran = sc->iter, first = sc->u_applied;
+    double tau[2];
+    int nv = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        if (e < f.n && first + e < ran) { tau[e] = sc->tau_ring[(first + e) & 7]; nv = e + 1; }
+        else tau[e] = 0.0;
+    switch (nv) {                      // wave-uniform: one straight-line body per entry count
+    case 1: uflush_body<VEC, 1>(u, count, f, tau); break;
+    case 2: uflush_body<VEC, 2>(u, count, f, tau); break;
+    default: break;
+    }
+}
+
+__global__ void k_umark(Scalars *sc, int n)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long want = sc->u_applied + n;
+    sc->u_applied = want < sc->iter ? want : sc->iter;
 }
 
 // y += a*x and d = b*d - g with host-supplied scalars (stand-alone entry points).
@@ -545,6 +631,7 @@ __global__ __launch_bounds__(64) void k_dot_strict(const double *__restrict__ v,
 // Fixed-order sum of `count` partials and the scalar recurrences.
 //   what 0: dq   = sum ; tau  = q0/dq                                  (cg.c:61-62)
 //   what 1: q1   = sum ; beta = q1/q0 ; q0 = q1 ; history ; stop rule  (cg.c:79-80,:89)
+//   what 4: as 1, for an iteration whose u update is deferred (sc->u_applied stays)
 //   what 2: q0   = sum ; q_init = q0 ; stop = rtol^2*q0                (cg.c:55)
 //   what 3: dot  = sum                                                 (stand-alone dot)
 // With `strict_src` the sum is taken from *strict_src (k_dot_strict's result)
@@ -554,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
                                                    const double *strict_src, Scalars *sc, int what,
                                                    double rtol, double *hist, long hist_cap)
 {
-    if (what < 2 && sc->done) return;
+    if ((what < 2 || what == 4) && sc->done) return;
     __shared__ double wave_slots[kWaves];
     double acc = 0.0;
     if (strict_src == nullptr)
@@ -565,13 +652,15 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
     if (what == 0) {
         sc->dq = s;
         sc->tau = sc->q0 / s;
-    } else if (what == 1) {
+        sc->tau_ring[sc->iter & 7] = sc->tau;
+    } else if (what == 1 || what == 4) {
         sc->q1 = s;
         sc->beta = s / sc->q0;
         sc->q0 = s;
         const long long it = sc->iter;
         if (hist != nullptr && it < hist_cap) hist[it] = s;
         sc->iter = it + 1;
+        if (what == 1) sc->u_applied = it + 1;
         if (sc->stop > 0.0 && s <= sc->stop) sc->done = 1;
     } else if (what == 2) {
         sc->q0 = s;
@@ -579,6 +668,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
         sc->q_init = s;
         sc->stop = rtol * rtol * s;
         sc->iter = 0;
+        sc->u_applied = 0;
         sc->done = 0;
     } else {
         sc->dot = s;

@@ -122,6 +122,7 @@ int flat_blocks(long nvec, long want)
 struct TileGeom {
     int contig = 0;   // 1: halo rows are contiguous with the block (solver context layout)
     int pf = 4;       // rows of loads in flight per thread
+    int pf_read = 0;  // same for the read-only pass of the lean schedule (0 = as pf)
     int vec;          // 2 when rows are 16-byte aligned (even G), else 1
     int nstrips;
     int tile_h;
@@ -169,14 +170,19 @@ void launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
     if (nrt <= 0) return;
     StencilArgs a = a0;
     a.ntiles_launch = nrt * t.nstrips;
-    const long nwg = (t.max_wgs > 0 && t.max_wgs < a.ntiles_launch) ? t.max_wgs : a.ntiles_launch;
+    // The read-only pass gets two workgroups per CU: measured 6.6 TB/s against 5.6 with one.
+    const long cap = (MODE == 3) ? 2 * t.max_wgs : t.max_wgs;
+    const long nwg = (cap > 0 && cap < a.ntiles_launch) ? cap : a.ntiles_launch;
     const dim3 grid((unsigned)nwg), block(kBlock);
 #define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C>), grid, block, 0, s, a)
     if (!t.contig) {                  // stand-alone entry point: caller-supplied halo pointers
         if (t.vec == 2) CG_LAUNCH(2, 4, false);
         else CG_LAUNCH(1, 4, false);
     } else if (t.vec == 2) {
-        switch (t.pf) {
+        // A pure read stream (MODE 3) needs about twice the bytes in flight of the mixed ones to
+        // cover HBM latency at its higher rate: double the depth there.
+        const int pf = (MODE == 3 && t.pf_read > 0) ? t.pf_read : t.pf;
+        switch (pf) {
         case 1: CG_LAUNCH(2, 1, true); break;
         case 4: CG_LAUNCH(2, 4, true); break;
         case 8: CG_LAUNCH(2, 8, true); break;
@@ -207,16 +213,22 @@ struct cg_ctx {
     int remap = 1;
     long flat_blocks_opt = 0;
     int prefetch = 4;
+    int prefetch_read = 0;                // read-only pass of the lean schedule; 0 = twice `prefetch`, at most 8
     long tile_wgs = 0;
     bool graph_explicit = false;          // the caller set CG_OPT_GRAPH_ITERS
 
     // device state
     hipStream_t stream = nullptr;
     double *u = nullptr, *g = nullptr, *q = nullptr;
-    double *g_alloc = nullptr, *d_alloc[2] = {nullptr, nullptr};   // g and d[] point one row into these
+    static constexpr int kMaxSlots = 2;
+    double *g_alloc[2] = {nullptr, nullptr};                       // g_buf[] and d[] point one row into these
+    double *d_alloc[kMaxSlots] = {nullptr};
+    double *g_buf[2] = {nullptr, nullptr};                         // the lean schedule alternates between two gradients
+    int gcur = 0;                                                  // which of g_buf[] is `g`
+    size_t front_elems = 0;                                        // doubles between an allocation's start and row 0
     double *u_alloc = nullptr, *q_alloc = nullptr;
     size_t padded_bytes = 0;              // size of each of those allocations
-    double *d[2] = {nullptr, nullptr};
+    double *d[kMaxSlots] = {nullptr};     // two direction buffers: the fused and lean schedules alternate
     int dcur = 0;                         // which of d[] holds the current direction
     bool pending_dupdate = false;         // fused schedules: last d update not yet applied
     double *partials = nullptr;           // 2 * npart doubles (d.q | g.g)
@@ -231,7 +243,7 @@ struct cg_ctx {
     bool q_valid = true;
 
     // halo rows (multi-GPU).  *_top = the row above the block, *_bot = below.
-    double *halo_d[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [buffer][top/bot]
+    double *halo_d[kMaxSlots][2] = {{nullptr, nullptr}};               // [buffer][top/bot]
     double *halo_g[2] = {nullptr, nullptr};
     cg::Comm *comm = nullptr;
     hipStream_t comm_stream = nullptr;    // halo exchange runs here, beside the interior stencil
@@ -240,13 +252,23 @@ struct cg_ctx {
     // captured iteration body
     hipGraphExec_t graph = nullptr;
     long graph_len = 0;                   // iterations in the captured graph
-    int graph_sched = -1, graph_reduce = -1, graph_dcur = -1;
+    int graph_sched = -1, graph_reduce = -1, graph_dcur = -1, graph_gcur = -1;
+    // lean schedule, host view while enqueueing: iterations whose tau*d is not yet in u (0 or 1;
+    // the newest direction is d[dcur]).  Every second iteration applies its own and the previous one.
+    int lean_pending = 0;
     Scalars *host_sc = nullptr;           // pinned read-back buffer
 
+    bool lean_unavailable = false;        // not enough free HBM for the lean schedule's second gradient buffer
     int effective_schedule() const
     {
         if (schedule >= 0) return schedule;
-        return reduce == CG_REDUCE_STRICT ? CG_SCHED_FUSED : CG_SCHED_FUSED_NOQ;   // strict order needs q stored
+        if (reduce == CG_REDUCE_STRICT) return CG_SCHED_FUSED;                     // strict order needs q stored
+        return lean_unavailable ? CG_SCHED_FUSED_NOQ : CG_SCHED_LEAN;
+    }
+    void set_gcur(int k)
+    {
+        gcur = k; g = g_buf[k];
+        halo_g[0] = g - G; halo_g[1] = g + count;
     }
     bool has_top() const { return row0 > 0; }
     bool has_bot() const { return row0 + rows < G; }
@@ -258,6 +280,7 @@ TileGeom ctx_geom(const cg_ctx *c)
 {
     TileGeom t = tile_geom(c->G, c->rows, true, c->tile_h);
     t.pf = c->prefetch;
+    t.pf_read = c->prefetch_read > 0 ? c->prefetch_read : (c->prefetch >= 4 ? 8 : 2 * c->prefetch);
     if (c->tile_wgs > 0) t.max_wgs = c->tile_wgs;
     t.contig = 1;
     return t;
@@ -308,7 +331,8 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
     } else if (c->nranks > 1) {
         // local fixed-order sum -> all ranks' sums (RCCL all-gather) -> rank-order sum
         double *mine = c->comm->gather_buf() + c->rank;
-        hipLaunchKernelGGL(cg::k_partial_sum, dim3(1), dim3(kBlock), 0, s, partials, npart, what < 2 ? c->sc : nullptr, mine);
+        hipLaunchKernelGGL(cg::k_partial_sum, dim3(1), dim3(kBlock), 0, s, partials, npart,
+                           (what < 2 || what == 4) ? c->sc : nullptr, mine);
         CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
         hipLaunchKernelGGL(cg::k_rank_sum, dim3(1), dim3(64), 0, s, c->comm->gather_buf(), c->nranks, c->strict_slot);
         src = c->strict_slot;
@@ -329,10 +353,77 @@ StencilArgs base_args(cg_ctx *c, const TileGeom &t)
     return a;
 }
 
+// u updates the lean schedule still owes when a solve ends (at most two): u += tau*d, oldest first.
+int enqueue_uflush(cg_ctx *c, int pending, int newest_slot)
+{
+    if (pending <= 0) return CG_OK;
+    if (pending > 2) return fail(CG_ERR_STATE, "lean schedule: %d deferred u updates", pending);
+    const TileGeom t = ctx_geom(c);
+    const int fb = flat_blocks(c->count / t.vec, c->flat_blocks_opt);
+    cg::UFlushArgs f;
+    memset(&f, 0, sizeof f);
+    f.n = pending;
+    for (int e = 0; e < pending; ++e) f.d[e] = c->d[(newest_slot + (pending - 1 - e)) & 1];
+    if (t.vec == 2) hipLaunchKernelGGL(cg::k_uflush<2>, dim3(fb), dim3(kBlock), 0, c->stream, c->u, c->count, f, c->sc);
+    else hipLaunchKernelGGL(cg::k_uflush<1>, dim3(fb), dim3(kBlock), 0, c->stream, c->u, c->count, f, c->sc);
+    hipLaunchKernelGGL(cg::k_umark, dim3(1), dim3(1), 0, c->stream, c->sc, pending);
+    HIPCHK(hipGetLastError());
+    return CG_OK;
+}
+
+// Steady-state iteration of the lean schedule.  State on entry: d[dcur] = d_{i-1}, g = g_i,
+// beta_i on the device; d_i = beta_i*d_{i-1} - g_i is never loaded back before it is used:
+//   pass 1 (reads d_{i-1}, g_i):            d_i on the fly, partials of d_i . A d_i       -> tau_i
+//   pass 2 (reads d_{i-1}, g_i once more):  d_i again -> the other direction buffer,
+//                                           g_{i+1} = g_i + tau_i*A d_i -> other gradient buffer,
+//                                           partials of g_{i+1} . g_{i+1}                 -> beta_{i+1}
+//   every second pass 2 also:               u = (u + tau_{i-1}*d_{i-1}) + tau_i*d_i  (both operands are at hand)
+// 16 + 32 + 16/2 = 56 B per point against 64 for the schedule that stores d' between the passes, and
+// pass 1 is a pure read stream.  Same arithmetic in the same order: bit-identical vectors.
+int enqueue_lean_iteration(cg_ctx *c)
+{
+    hipStream_t s = c->stream;
+    const TileGeom t = ctx_geom(c);
+    double *p_dq = c->partials, *p_gg = c->partials + c->npart;
+    if (c->nranks > 1)      // g's boundary rows; d's halo rows are kept current locally
+        CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
+    const int in = c->dcur, out = c->dcur ^ 1;
+    StencilArgs a = base_args(c, t);
+    a.partials = p_dq;
+    a.d_in = c->d[in]; a.g = c->g;
+    a.d_top = c->has_top() ? c->halo_d[in][0] : nullptr;
+    a.d_bot = c->has_bot() ? c->halo_d[in][1] : nullptr;
+    a.g_top = c->has_top() ? c->halo_g[0] : nullptr;
+    a.g_bot = c->has_bot() ? c->halo_g[1] : nullptr;
+    launch_stencil<3, false>(t, a, s);
+    HIPCHK(hipGetLastError());
+    CGCHK(enqueue_dot_finish(c, nullptr, nullptr, p_dq, t.ntiles, 0, 0.0));
+    StencilArgs b = a;
+    b.partials = p_gg;
+    b.d_out = c->d[out];
+    b.d_top_out = c->has_top() ? c->halo_d[out][0] : nullptr;
+    b.d_bot_out = c->has_bot() ? c->halo_d[out][1] : nullptr;
+    b.g_out = c->g_buf[c->gcur ^ 1];
+    b.u = c->u;
+    const bool with_u = c->lean_pending == 1;             // the previous iteration's u update is outstanding: do both
+    if (with_u) launch_stencil<5, false>(t, b, s);
+    else launch_stencil<4, false>(t, b, s);
+    HIPCHK(hipGetLastError());
+    CGCHK(enqueue_dot_finish(c, nullptr, nullptr, p_gg, t.ntiles, with_u ? 1 : 4, 0.0));
+    c->dcur = out;
+    c->set_gcur(c->gcur ^ 1);
+    c->lean_pending = with_u ? 0 : 1;
+    return CG_OK;
+}
+
 int enqueue_iteration(cg_ctx *c, bool first)
 {
     hipStream_t s = c->stream;
-    const int sched = c->effective_schedule();
+    int sched = c->effective_schedule();
+    if (sched == CG_SCHED_LEAN) {
+        if (!first) return enqueue_lean_iteration(c);
+        sched = CG_SCHED_FUSED_NOQ;       // d is materialised: stencil pass + in-place update pass, as there
+    }
     const TileGeom t = ctx_geom(c);
     double *p_dq = c->partials, *p_gg = c->partials + c->npart;
     const long nvec = c->count / t.vec;
@@ -455,6 +546,28 @@ int flush_pending_dupdate(cg_ctx *c)
     return CG_OK;
 }
 
+// Lean schedule set-up: the second gradient buffer (with its guard rows, zero-filled) is
+// allocated on first use.  Without enough free HBM an automatically chosen schedule falls
+// back to FUSED_NOQ; an explicitly requested LEAN fails.
+int lean_setup(cg_ctx *c)
+{
+    if (c->g_alloc[1]) return CG_OK;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    hipError_t e = hipErrorOutOfMemory;
+    if (c->padded_bytes + ((size_t)1 << 30) <= free_b) e = hipMalloc(&c->g_alloc[1], c->padded_bytes);
+    if (e != hipSuccess) {
+        c->g_alloc[1] = nullptr;
+        (void)hipGetLastError();
+        if (c->schedule < 0) { c->lean_unavailable = true; drop_graph(c); return CG_OK; }
+        return fail(CG_ERR_HIP, "lean schedule: no room for a second gradient buffer (%zu bytes, %zu free)", c->padded_bytes, free_b);
+    }
+    HIPCHK(hipMemset(c->g_alloc[1], 0, c->padded_bytes));
+    HIPCHK(hipStreamSynchronize(nullptr));               // the fill ran on the null stream
+    c->g_buf[1] = c->g_alloc[1] + c->front_elems;
+    return CG_OK;
+}
+
 // Capture `len` iterations (none of them the first) into a graph.  Fused
 // schedules swap d's buffers every iteration, so len is forced even and the
 // buffer roles are the same at every replay.
@@ -463,13 +576,16 @@ int build_graph(cg_ctx *c, long len)
     drop_graph(c);
     const int sched = c->effective_schedule();
     if (sched != CG_SCHED_CLASSIC && (len & 1)) ++len;
+    // (lean: direction buffer, gradient buffer and the paired u update all have period 2)
     hipGraph_t graph = nullptr;
-    const int dcur0 = c->dcur;
+    const int dcur0 = c->dcur, gcur0 = c->gcur, pend0 = c->lean_pending;
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = CG_OK;
     for (long i = 0; i < len && rc == CG_OK; ++i) rc = enqueue_iteration(c, false);
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
     c->dcur = dcur0;                       // capture executed nothing
+    c->set_gcur(gcur0);
+    c->lean_pending = pend0;
     if (rc != CG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(CG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
     e = hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0);
@@ -479,6 +595,7 @@ int build_graph(cg_ctx *c, long len)
     c->graph_sched = sched;
     c->graph_reduce = c->reduce;
     c->graph_dcur = dcur0;
+    c->graph_gcur = gcur0;
     return CG_OK;
 }
 
@@ -698,19 +815,20 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
     // allocations measured ~10 % faster in the update kernel than mixed offsets)
     c->padded_bytes = padded;
     alloc(&c->u_alloc, padded); alloc(&c->q_alloc, padded);
-    alloc(&c->g_alloc, padded); alloc(&c->d_alloc[0], padded); alloc(&c->d_alloc[1], padded);
+    c->front_elems = (size_t)front;
+    alloc(&c->g_alloc[0], padded); alloc(&c->d_alloc[0], padded); alloc(&c->d_alloc[1], padded);
     alloc(&c->partials, 2 * (size_t)c->npart * sizeof(double));
     alloc(&c->strict_slot, 256);
     alloc(reinterpret_cast<double **>(&c->sc), sizeof(Scalars));
     if (rc == CG_OK) {
         c->u = c->u_alloc + front; c->q = c->q_alloc + front;
-        c->g = c->g_alloc + front;
-        c->halo_g[0] = c->g - G; c->halo_g[1] = c->g + c->count;
+        c->g_buf[0] = c->g_alloc[0] + front;
+        c->set_gcur(0);
         for (int b = 0; b < 2; ++b) {
             c->d[b] = c->d_alloc[b] + front;
             c->halo_d[b][0] = c->d[b] - G; c->halo_d[b][1] = c->d[b] + c->count;
         }
-        if (hipMemset(c->g_alloc, 0, padded) != hipSuccess || hipMemset(c->d_alloc[0], 0, padded) != hipSuccess ||
+        if (hipMemset(c->g_alloc[0], 0, padded) != hipSuccess || hipMemset(c->d_alloc[0], 0, padded) != hipSuccess ||
             hipMemset(c->d_alloc[1], 0, padded) != hipSuccess)
             rc = fail(CG_ERR_HIP, "hipMemset of the padded vectors failed");
     }
@@ -736,8 +854,8 @@ int cg_destroy(cg_ctx *c)
     drop_graph(c);
     delete c->comm;
     c->xs.release();
-    (void)hipFree(c->u_alloc); (void)hipFree(c->g_alloc); (void)hipFree(c->q_alloc);
-    (void)hipFree(c->d_alloc[0]); (void)hipFree(c->d_alloc[1]);
+    (void)hipFree(c->u_alloc); (void)hipFree(c->g_alloc[0]); (void)hipFree(c->g_alloc[1]); (void)hipFree(c->q_alloc);
+    for (double *p : c->d_alloc) (void)hipFree(p);
     (void)hipFree(c->partials); (void)hipFree(c->strict_slot); (void)hipFree(c->sc); (void)hipFree(c->hist);
     if (c->host_sc) (void)hipHostFree(c->host_sc);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -756,7 +874,7 @@ int cg_set_option(cg_ctx *c, int key, long value)
         if (value != CG_REDUCE_FAST && value != CG_REDUCE_STRICT) return fail(CG_ERR_ARG, "unknown reduction order %ld", value);
         c->reduce = (int)value; break;
     case CG_OPT_SCHEDULE:
-        if (value < -1 || value > CG_SCHED_FUSED_NOQ) return fail(CG_ERR_ARG, "unknown schedule %ld", value);
+        if (value < -1 || value > CG_SCHED_LEAN) return fail(CG_ERR_ARG, "unknown schedule %ld", value);
         c->schedule = (int)value; break;
     case CG_OPT_TILE_H:
         if (value < 0) return fail(CG_ERR_ARG, "tile height must be >= 0");
@@ -771,6 +889,9 @@ int cg_set_option(cg_ctx *c, int key, long value)
     case CG_OPT_PREFETCH:
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(CG_ERR_ARG, "prefetch depth must be 1, 2, 4 or 8");
         c->prefetch = (int)value; break;
+    case CG_OPT_PREFETCH_READ:
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(CG_ERR_ARG, "prefetch depth must be 0, 1, 2, 4 or 8");
+        c->prefetch_read = (int)value; break;
     case CG_OPT_TILE_WGS:
         if (value < 0) return fail(CG_ERR_ARG, "workgroup cap must be >= 0");
         c->tile_wgs = value; break;
@@ -783,6 +904,25 @@ int cg_set_option(cg_ctx *c, int key, long value)
     return CG_OK;
 }
 
+int cg_get_option(cg_ctx *c, int key, long *value)
+{
+    if (!c || !value) return fail(CG_ERR_ARG, "cg_get_option: NULL argument");
+    switch (key) {
+    case CG_OPT_REDUCE: *value = c->reduce; break;
+    case CG_OPT_SCHEDULE: *value = c->effective_schedule(); break;      // what the next solve will run
+    case CG_OPT_TILE_H: *value = ctx_geom(c).tile_h; break;
+    case CG_OPT_GRAPH_ITERS: *value = c->graph_iters; break;
+    case CG_OPT_XCD_REMAP: *value = c->remap; break;
+    case CG_OPT_FLAT_BLOCKS: *value = c->flat_blocks_opt; break;
+    case CG_OPT_PREFETCH: *value = c->prefetch; break;
+    case CG_OPT_PREFETCH_READ: *value = ctx_geom(c).pf_read; break;
+    case CG_OPT_STRICT_IMPL: *value = c->strict_impl; break;
+    case CG_OPT_TILE_WGS: *value = ctx_geom(c).max_wgs; break;
+    default: return fail(CG_ERR_ARG, "unknown option key %d", key);
+    }
+    return CG_OK;
+}
+
 int cg_init_problem(cg_ctx *c)
 {
     if (!c) return fail(CG_ERR_ARG, "cg_init_problem: ctx is NULL");
@@ -791,6 +931,8 @@ int cg_init_problem(cg_ctx *c)
     const double h = (double)1 / (double)c->n;           // utils.c:323
     const size_t bytes = (size_t)c->count * sizeof(double);
     c->dcur = 0;
+    c->set_gcur(0);
+    c->lean_pending = 0;
     c->pending_dupdate = false;
     c->q_valid = true;
     HIPCHK(hipMemsetAsync(c->u, 0, bytes, s));           // calloc, cg.c:44
@@ -813,10 +955,11 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     if (!c || !out) return fail(CG_ERR_ARG, "cg_solve: NULL argument");
     if (max_iters < 0 || rtol < 0) return fail(CG_ERR_ARG, "cg_solve: max_iters and rtol must be >= 0");
     CGCHK(select_device(c->device));
-    const int sched = c->effective_schedule();
-    if (c->reduce == CG_REDUCE_STRICT && sched == CG_SCHED_FUSED_NOQ)
+    if (c->reduce == CG_REDUCE_STRICT && (c->effective_schedule() == CG_SCHED_FUSED_NOQ || c->effective_schedule() == CG_SCHED_LEAN))
         return fail(CG_ERR_STATE, "strict reduction order needs a schedule that stores q (CLASSIC or FUSED)");
     if (c->nranks > 1 && !c->comm) return fail(CG_ERR_STATE, "multi-rank context without cg_comm_init");
+    if (c->effective_schedule() == CG_SCHED_LEAN) CGCHK(lean_setup(c));   // may fall back to FUSED_NOQ (auto schedule only)
+    const int sched = c->effective_schedule();
     hipStream_t s = c->stream;
 
     if (c->reduce == CG_REDUCE_STRICT && use_parallel_strict(c->strict_impl, c->count)) {
@@ -840,7 +983,8 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     // the host-staged transport synchronises the stream and cannot be captured at all.
     if (c->nranks > 1 && (!c->graph_explicit || !c->comm->stream_ordered())) glen = 0;
     if (glen > 0 && max_iters - 1 >= glen) {
-        if (!c->graph || c->graph_sched != sched || c->graph_reduce != c->reduce || c->graph_dcur != c->dcur)
+        if (!c->graph || c->graph_sched != sched || c->graph_reduce != c->reduce || c->graph_dcur != c->dcur ||
+            (sched == CG_SCHED_LEAN && c->graph_gcur != c->gcur))
             CGCHK(build_graph(c, glen));
     } else {
         glen = 0;
@@ -861,7 +1005,8 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         }
         CGCHK(enqueue_dot_finish(c, c->g, c->g, c->partials, fb, 2, rtol));
     }
-    const int dcur_start = c->dcur;
+    const int dcur_start = c->dcur, gcur_start = c->gcur;
+    c->lean_pending = 0;
     long launched = 0;
     bool stopped = false;
     // Iteration 0 runs eagerly: the fused schedules have no d update to fold in yet.
@@ -890,7 +1035,19 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     const Scalars &h = *c->host_sc;
     // Fused schedules flip d's buffers once per executed iteration after the first;
     // iterations skipped because the stop rule fired did not flip anything.
-    if (sched != CG_SCHED_CLASSIC) {
+    if (sched == CG_SCHED_LEAN) {
+        // Iteration 0 worked in place; each later one moved to the next direction buffer and
+        // the other gradient buffer.  Iterations skipped behind a fired stop rule moved nothing.
+        const long executed = (long)h.iter, moved = executed >= 1 ? executed - 1 : 0;
+        c->dcur = dcur_start ^ (int)(moved & 1);
+        c->set_gcur(gcur_start ^ (int)(moved & 1));
+        CGCHK(enqueue_uflush(c, (int)(executed - (long)h.u_applied), c->dcur));   // u updates still outstanding
+        c->lean_pending = 0;
+        c->pending_dupdate = executed >= 1;
+        CGCHK(flush_pending_dupdate(c));
+        HIPCHK(hipStreamSynchronize(s));
+        c->q_valid = false;
+    } else if (sched != CG_SCHED_CLASSIC) {
         const long executed = (long)h.iter;
         c->dcur = (executed >= 1) ? (dcur_start ^ (int)((executed - 1) & 1)) : dcur_start;
         c->pending_dupdate = executed >= 1;
@@ -954,13 +1111,28 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     const long nvec = c->count / t.vec;
     const int fb = flat_blocks(nvec, c->flat_blocks_opt);
     // Give the prologue scalars harmless values: tau = 0 and beta = 1 keep the data bounded.
+    if (sched == CG_SCHED_LEAN) CGCHK(lean_setup(c));
+    if (c->effective_schedule() != sched) return fail(CG_ERR_HIP, "lean schedule: not enough free HBM");
     Scalars hs;
     memset(&hs, 0, sizeof hs);
     hs.q0 = 1.0; hs.tau = 0.0; hs.beta = 1.0;
+    hs.iter = 1LL << 40;                                // every deferred u entry counts as "ran"
     HIPCHK(hipMemcpy(c->sc, &hs, sizeof hs, hipMemcpyHostToDevice));
     double per_point = 0.0;
     auto launch = [&]() {
-        if (which == 0) {
+        if (sched == CG_SCHED_LEAN) {
+            StencilArgs a = base_args(c, t);
+            const int out = c->dcur ^ 1;
+            a.partials = c->partials; a.d_in = c->d[c->dcur]; a.g = c->g;
+            if (which == 0) {
+                launch_stencil<3, false>(t, a, s);
+            } else {
+                a.partials = c->partials + c->npart; a.d_out = c->d[out]; a.g_out = c->g_buf[c->gcur ^ 1]; a.u = c->u;
+                if (which == 1) launch_stencil<4, false>(t, a, s);
+                else launch_stencil<5, false>(t, a, s);
+                c->dcur = out; c->set_gcur(c->gcur ^ 1);
+            }
+        } else if (which == 0) {
             StencilArgs a = base_args(c, t);
             a.partials = c->partials; a.q = c->q;
             if (sched == CG_SCHED_CLASSIC) {
@@ -987,7 +1159,12 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
             else hipLaunchKernelGGL(cg::k_dupdate<1>, dim3(fb), dim3(kBlock), 0, s, c->d[c->dcur], c->g, c->count, c->sc, 0);
         }
     };
-    if (which == 0) per_point = sched == CG_SCHED_CLASSIC ? 16.0 : (sched == CG_SCHED_FUSED ? 32.0 : 24.0);
+    if (sched == CG_SCHED_LEAN) {
+        if (which == 0) per_point = 16.0;                               // R d, g
+        else if (which == 1) per_point = 32.0;                          // R d, g  W d', g'
+        else if (which == 2) per_point = 48.0;                          // ... and R u  W u (every second iteration)
+        else return fail(CG_ERR_ARG, "unknown kernel id %d", which);
+    } else if (which == 0) per_point = sched == CG_SCHED_CLASSIC ? 16.0 : (sched == CG_SCHED_FUSED ? 32.0 : 24.0);
     else if (which == 1) per_point = sched == CG_SCHED_FUSED_NOQ ? 40.0 : 48.0;
     else if (which == 2) {
         if (sched != CG_SCHED_CLASSIC) return fail(CG_ERR_STATE, "the fused schedules have no separate d-update kernel");

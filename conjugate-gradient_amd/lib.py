@@ -13,17 +13,20 @@ LIB_PATH = os.environ.get("CG_HIP_LIB") or os.path.join(_HERE, "libcg_hip.so")  
 # status codes / enums of include/cg_hip.h
 CG_OK = 0
 REDUCE_FAST, REDUCE_STRICT = 0, 1
-SCHED_CLASSIC, SCHED_FUSED, SCHED_FUSED_NOQ = 0, 1, 2
+SCHED_CLASSIC, SCHED_FUSED, SCHED_FUSED_NOQ, SCHED_LEAN = 0, 1, 2, 3
 OPT_REDUCE, OPT_SCHEDULE, OPT_TILE_H, OPT_GRAPH_ITERS, OPT_XCD_REMAP, OPT_FLAT_BLOCKS, OPT_PREFETCH = 1, 2, 3, 4, 5, 6, 7
 OPT_STRICT_IMPL = 8
 OPT_TILE_WGS = 9
+OPT_PREFETCH_READ = 11
 STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL = 1, 2, 3
 VEC_U, VEC_G, VEC_D, VEC_Q = 0, 1, 2, 3
 
 # Algorithmic HBM bytes per grid point per iteration of each schedule
 # (fp64 accesses x 8): stencil kernel + update kernel (+ d-update kernel).
-SCHED_BYTES_PER_POINT = {SCHED_CLASSIC: 16 + 48 + 24, SCHED_FUSED: 32 + 48, SCHED_FUSED_NOQ: 24 + 40}
-SCHED_NAMES = {SCHED_CLASSIC: "classic", SCHED_FUSED: "fused", SCHED_FUSED_NOQ: "fused_noq"}
+# (LEAN: R d,g | R d,g W d',g' | every second iteration R u W u)
+SCHED_BYTES_PER_POINT = {SCHED_CLASSIC: 16 + 48 + 24, SCHED_FUSED: 32 + 48, SCHED_FUSED_NOQ: 24 + 40,
+                         SCHED_LEAN: 16 + 32 + 8}
+SCHED_NAMES = {SCHED_CLASSIC: "classic", SCHED_FUSED: "fused", SCHED_FUSED_NOQ: "fused_noq", SCHED_LEAN: "lean"}
 
 
 class CGError(RuntimeError):
@@ -55,6 +58,7 @@ SIGNATURES = {
     "cg_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int]),
     "cg_destroy": (C.c_int, [C.c_void_p]),
     "cg_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_long]),
+    "cg_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long)]),
     "cg_init_problem": (C.c_int, [C.c_void_p]),
     "cg_solve": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.POINTER(Result)]),
     "cg_copy_out": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),

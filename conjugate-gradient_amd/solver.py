@@ -117,22 +117,22 @@ class CGSolver:
         ctx = C.c_void_p()
         _l.check(self._lib.cg_create(C.byref(ctx), self.device, self.n, self.row0, self.rows, self.rank, self.nranks))
         self._ctx = ctx
-        self.reduce, self.schedule = _l.REDUCE_FAST, _l.SCHED_FUSED_NOQ
+        self.reduce, self.schedule = _l.REDUCE_FAST, None          # None = the library picks (LEAN, FUSED when strict)
 
     # -- configuration ---------------------------------------------------
     def set_option(self, key, value):
         _l.check(self._lib.cg_set_option(self._ctx, key, int(value)))
 
     def configure(self, reduce=None, schedule=None, tile_h=None, graph_iters=None, xcd_remap=None,
-                  flat_blocks=None, prefetch=None, strict_impl=None, tile_wgs=None):
+                  flat_blocks=None, prefetch=None, strict_impl=None, tile_wgs=None, prefetch_read=None):
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
-            if schedule is None and reduce == _l.REDUCE_STRICT:
-                schedule = _l.SCHED_FUSED
+            if schedule is None and reduce == _l.REDUCE_STRICT and self.schedule in (_l.SCHED_FUSED_NOQ, _l.SCHED_LEAN):
+                schedule = -1                     # those do not store q: let the library pick (FUSED)
         if schedule is not None:
             self.set_option(_l.OPT_SCHEDULE, schedule)
-            self.schedule = schedule
+            self.schedule = schedule if schedule >= 0 else None
         if tile_h is not None:
             self.set_option(_l.OPT_TILE_H, tile_h)
         if graph_iters is not None:
@@ -147,11 +147,24 @@ class CGSolver:
             self.set_option(_l.OPT_STRICT_IMPL, strict_impl)
         if tile_wgs is not None:
             self.set_option(_l.OPT_TILE_WGS, tile_wgs)
+        if prefetch_read is not None:
+            self.set_option(_l.OPT_PREFETCH_READ, prefetch_read)
         return self
+
+    def get_option(self, key):
+        v = C.c_long(0)
+        _l.check(self._lib.cg_get_option(self._ctx, key, C.byref(v)))
+        return v.value
+
+    @property
+    def effective_schedule(self):
+        """The schedule the next solve runs (after a solve: the one it ran)."""
+        return self.get_option(_l.OPT_SCHEDULE)
 
     @property
     def bytes_per_point(self):
-        return _l.SCHED_BYTES_PER_POINT[self.schedule]
+        """Algorithmic HBM bytes per grid point per iteration of the schedule in effect."""
+        return _l.SCHED_BYTES_PER_POINT[self.effective_schedule]
 
     # -- multi-GPU -------------------------------------------------------
     @staticmethod

@@ -87,10 +87,13 @@ typedef struct cg_ctx cg_ctx;
 #define CG_SCHED_CLASSIC  0    /* stencil+d.q | u,g update+g.g | d update        : 88 B/point */
 #define CG_SCHED_FUSED    1    /* d update fused into the stencil kernel         : 80 B/point */
 #define CG_SCHED_FUSED_NOQ 2   /* ... and q recomputed in the update kernel      : 64 B/point */
+#define CG_SCHED_LEAN     3    /* d' = beta*d - g recomputed in both passes instead of stored and re-read,
+                                  u updated for two iterations at a time           : 56 B/point
+                                  (fast order only; needs a second gradient buffer) */
 
 /* Option keys for cg_set_option. */
 #define CG_OPT_REDUCE      1   /* CG_REDUCE_*                        default FAST     */
-#define CG_OPT_SCHEDULE    2   /* CG_SCHED_*                         default FUSED_NOQ (FUSED when strict: q must be stored) */
+#define CG_OPT_SCHEDULE    2   /* CG_SCHED_*                         default LEAN (FUSED when strict: q must be stored) */
 #define CG_OPT_TILE_H      3   /* rows per stencil tile, 0 = auto                     */
 #define CG_OPT_GRAPH_ITERS 4   /* iterations captured per hipGraph, 0 = no graph; default 10 */
 #define CG_OPT_XCD_REMAP   5   /* 1 = XCD-aware tile order (default), 0 = plain order  */
@@ -98,6 +101,7 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_PREFETCH    7   /* rows of loads each thread keeps in flight: 1, 2, 4 (default) or 8 */
 #define CG_OPT_STRICT_IMPL 8   /* how the strict order is evaluated: 1 = auto (default), 2 = literal
                                   one-accumulator replay, 3 = parallel evaluation (same bits, see cg_dot) */
+#define CG_OPT_PREFETCH_READ 11 /* same for LEAN's read-only pass; 0 = twice CG_OPT_PREFETCH, at most 8 (default) */
 #define CG_OPT_TILE_WGS    9   /* cap on workgroups per tiled launch; with more tiles than that each
                                   workgroup walks several tiles in turn.  0 = auto (256 with automatic
                                   tile height, one workgroup per tile with an explicit CG_OPT_TILE_H) */
@@ -107,6 +111,9 @@ typedef struct cg_ctx cg_ctx;
 int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks);
 int cg_destroy(cg_ctx *ctx);
 int cg_set_option(cg_ctx *ctx, int key, long value);
+/* Current value of an option; for CG_OPT_SCHEDULE, CG_OPT_TILE_H, CG_OPT_TILE_WGS and
+ * CG_OPT_U_DEFER the value in effect after automatic selection. */
+int cg_get_option(cg_ctx *ctx, int key, long *value);
 
 /* u = 0, q = 0, d = d0, g = -d0 (cg.c:41-45 via utils.c:276-350).            */
 int cg_init_problem(cg_ctx *ctx);

@@ -61,7 +61,8 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast"):
     G = n + 1
     row0, rows = cg.dist.partition(G, tr.world, tr.rank)
     s = cg.CGSolver(n, device=0, row0=row0, rows=rows, rank=tr.rank, nranks=tr.world)
-    s.configure(schedule={"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[schedule])
+    s.configure(schedule={"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ,
+                          "lean": cg.SCHED_LEAN}[schedule])
     if order != "fast":                           # one accumulator handed from rank to rank
         s.configure(reduce=cg.REDUCE_STRICT, schedule=s.schedule,
                     strict_impl={"strict": cg.STRICT_AUTO, "strict_replay": cg.STRICT_REPLAY,

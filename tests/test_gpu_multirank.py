@@ -10,7 +10,7 @@ from dist_launch import run_ranks, stack
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("schedule", ["classic", "fused", "fused_noq"])
+@pytest.mark.parametrize("schedule", ["classic", "fused", "fused_noq", "lean"])
 @pytest.mark.parametrize("world,n,iters", [(2, 255, 60), (4, 255, 60), (4, 1023, 120), (2, 20, 12)])
 def test_multirank_matches_single_rank(oracle, tmp_path, schedule, world, n, iters):
     if (n + 1) % world:
@@ -31,7 +31,7 @@ def test_multirank_matches_single_rank(oracle, tmp_path, schedule, world, n, ite
 
 def test_multirank_stop_rule(oracle, tmp_path):
     n = 63
-    res = run_ranks(4, ["gpu", n, 10000, tmp_path, "fused_noq", 1e-8], tmp_path)
+    res = run_ranks(4, ["gpu", n, 10000, tmp_path, "lean", 1e-8], tmp_path)
     ref = oracle.cg(n, 10000, rtol=1e-8)
     assert all(int(r["converged"]) == 1 for r in res)
     assert len({int(r["iters"]) for r in res}) == 1

@@ -167,11 +167,14 @@ def test_strict_solve_with_and_without_graph_identical(cg):
     assert np.array_equal(bits(a.vector(cg.VEC_U)), bits(b.vector(cg.VEC_U)))
 
 
-@pytest.mark.parametrize("sched", ["classic", "fused", "fused_noq"])
+SCHEDS = {"classic": "SCHED_CLASSIC", "fused": "SCHED_FUSED", "fused_noq": "SCHED_FUSED_NOQ", "lean": "SCHED_LEAN"}
+
+
+@pytest.mark.parametrize("sched", ["classic", "fused", "fused_noq", "lean"])
 @pytest.mark.parametrize("n,iters", [(20, 12), (63, 50), (255, 200), (256, 200), (1023, 200)])
 def test_fast_solve_within_tolerance_of_reference(cg, oracle, golden, sched, n, iters):
     rec = golden[(n, iters, 1, 0.0)]
-    sid = {"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[sched]
+    sid = getattr(cg, SCHEDS[sched])
     s = cg.CGSolver(n).configure(reduce=cg.REDUCE_FAST, schedule=sid).init_problem()
     r = s.solve(iters)
     assert r.iters == iters
@@ -185,9 +188,9 @@ def test_fast_solve_within_tolerance_of_reference(cg, oracle, golden, sched, n, 
     assert abs(float(np.sum(u)) - float(rec["sum_u"])) <= FAST_U_RTOL * float(rec["sum_u"])
 
 
-@pytest.mark.parametrize("sched", ["classic", "fused", "fused_noq"])
+@pytest.mark.parametrize("sched", ["classic", "fused", "fused_noq", "lean"])
 def test_fast_solve_is_deterministic_and_graph_independent(cg, sched):
-    sid = {"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[sched]
+    sid = getattr(cg, SCHEDS[sched])
     outs = []
     for graph in (0, 4, 10, 10):
         s = cg.CGSolver(255).configure(schedule=sid, graph_iters=graph).init_problem()
@@ -203,7 +206,7 @@ def test_schedules_agree_bitwise_given_the_same_scalars(cg):
     # products' order, and after a single stencil + d.q (tile order, identical in
     # all schedules) u and g must agree bit for bit.
     res = []
-    for sid in (cg.SCHED_CLASSIC, cg.SCHED_FUSED, cg.SCHED_FUSED_NOQ):
+    for sid in (cg.SCHED_CLASSIC, cg.SCHED_FUSED, cg.SCHED_FUSED_NOQ, cg.SCHED_LEAN):
         s = cg.CGSolver(255).configure(schedule=sid, graph_iters=0).init_problem()
         s.solve(1)
         res.append((bits(s.vector(cg.VEC_U)).copy(), bits(s.vector(cg.VEC_G)).copy()))
@@ -233,11 +236,43 @@ def test_stop_rule(cg, oracle, golden, mode):
     assert np.max(np.abs(s.vector(cg.VEC_U) - np.outer(x * (1 - x), x * (1 - x)))) < 5e-11
 
 
-@pytest.mark.parametrize("sched", ["fused", "fused_noq"])
+@pytest.mark.parametrize("graph", [0, 4, 10])
+@pytest.mark.parametrize("n", [63, 254, 255, 600])
+def test_lean_schedule_is_bit_identical_to_fused_noq(cg, n, graph):
+    # Same tiles, same per-thread order, same arithmetic: recomputing d' in both passes and applying the
+    # u updates two iterations at a time changes no bit of q1's history, u, g or d -- whatever the parity
+    # of the iteration count and its relation to the captured graph's length.
+    for iters in (1, 2, 3, 8, 9, 10, 17, 27, 57):
+        a = cg.CGSolver(n).configure(schedule=cg.SCHED_FUSED_NOQ, graph_iters=graph).init_problem()
+        b = cg.CGSolver(n).configure(schedule=cg.SCHED_LEAN, graph_iters=graph).init_problem()
+        ra, rb = a.solve(iters), b.solve(iters)
+        assert ra.iters == rb.iters == iters
+        assert np.array_equal(bits(a.history(iters)), bits(b.history(iters))), (iters, "history")
+        for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+            assert np.array_equal(bits(a.vector(which)), bits(b.vector(which))), (iters, which)
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("n", [63, 100])
+def test_lean_schedule_stop_rule_and_continuation_bitwise(cg, n):
+    a = cg.CGSolver(n).configure(schedule=cg.SCHED_FUSED_NOQ, graph_iters=10).init_problem()
+    b = cg.CGSolver(n).configure(schedule=cg.SCHED_LEAN, graph_iters=10).init_problem()
+    ra, rb = a.solve(10000, rtol=1e-8), b.solve(10000, rtol=1e-8)       # stops inside a captured graph
+    assert ra.converged and rb.converged and ra.iters == rb.iters
+    for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+        assert np.array_equal(bits(a.vector(which)), bits(b.vector(which))), which
+    for more in (1, 2, 5, 12):                                          # every ring / gradient-buffer parity
+        ra, rb = a.solve(more), b.solve(more)
+        assert float(ra.q1).hex() == float(rb.q1).hex()
+        for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+            assert np.array_equal(bits(a.vector(which)), bits(b.vector(which))), (more, which)
+
+
+@pytest.mark.parametrize("sched", ["fused", "fused_noq", "lean"])
 @pytest.mark.parametrize("split", [(13, 24), (14, 23), (1, 36), (36, 1), (2, 35)])
 def test_solve_can_be_continued(cg, sched, split):
     # the fused schedules ping-pong d between two buffers: every parity of the split must end in the right one
-    sid = {"fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ}[sched]
+    sid = getattr(cg, SCHEDS[sched])
     a = cg.CGSolver(255).configure(schedule=sid).init_problem()
     a.solve(split[0])
     ra = a.solve(split[1])

@@ -55,10 +55,10 @@ cfg = {}
 m = re.search(r'"grid": (\d+).*?"schedule": "(\w+)"', open(os.path.join(src, "trace.log")).read())
 if m:
     cfg = {"grid": int(m.group(1)), "schedule": m.group(2)}
-role = {"1": "stencil", "0": "stencil", "2": "update"}
+role = {"1": "stencil", "0": "stencil", "2": "update", "3": "pass1_dq", "4": "pass2_g", "5": "pass2_g_u"}
 kern = {}
 for k in dur:
-    mm = re.match(r"void cg::k_stencil<\d+, (\d), \w+, \d+>", k)
+    mm = re.match(r"void cg::k_stencil<\d+, (\d), \w+, \d+(?:, \w+)?>", k)
     name = role.get(mm.group(1)) if mm else ("update" if "k_update" in k else "dupdate" if "k_dupdate" in k else None)
     if name is None or not fetch.get(k) or not write.get(k) or len(dur[k]) < 10:
         continue
