@@ -102,7 +102,7 @@ def main():
                     help="iterations per captured hipGraph (default: 10 on one GPU; eager launches with RCCL)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="N > 1: RCCL inside the library, or host-staged rows over a gloo group (diagnostic)")
-    ap.add_argument("--prefetch", type=int, default=4)
+    ap.add_argument("--prefetch", type=int, default=0, help="rows of loads in flight per thread (0 = per-kernel defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses GPU 0, gloo process group, host-staged transport")

@@ -98,10 +98,11 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_GRAPH_ITERS 4   /* iterations captured per hipGraph, 0 = no graph; default 10 */
 #define CG_OPT_XCD_REMAP   5   /* 1 = XCD-aware tile order (default), 0 = plain order  */
 #define CG_OPT_FLAT_BLOCKS 6   /* workgroups of the flat (1-D) kernels, 0 = auto       */
-#define CG_OPT_PREFETCH    7   /* rows of loads each thread keeps in flight: 1, 2, 4 (default) or 8 */
+#define CG_OPT_PREFETCH    7   /* rows of loads each thread keeps in flight: 1, 2, 4 or 8 for every tiled
+                                  kernel; 0 = measured per-kernel defaults (default) */
 #define CG_OPT_STRICT_IMPL 8   /* how the strict order is evaluated: 1 = auto (default), 2 = literal
                                   one-accumulator replay, 3 = parallel evaluation (same bits, see cg_dot) */
-#define CG_OPT_PREFETCH_READ 11 /* same for LEAN's read-only pass; 0 = twice CG_OPT_PREFETCH, at most 8 (default) */
+#define CG_OPT_PREFETCH_READ 11 /* same for LEAN's read-only pass alone; 0 = default (8) */
 #define CG_OPT_TILE_WGS    9   /* cap on workgroups per tiled launch; with more tiles than that each
                                   workgroup walks several tiles in turn.  0 = auto (256 with automatic
                                   tile height, one workgroup per tile with an explicit CG_OPT_TILE_H) */

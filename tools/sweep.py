@@ -7,7 +7,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16383
 tiles = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 128, 256, 512, 1024]
 scheds = {"noq": cg.SCHED_FUSED_NOQ, "classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "lean": cg.SCHED_LEAN}
 which_s = sys.argv[3].split(",") if len(sys.argv) > 3 else ["noq"]
-pfs = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [4]
+pfs = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
 wgs = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
 extra = dict(kv.split("=") for kv in sys.argv[6].split(",")) if len(sys.argv) > 6 else {}     # e.g. u_defer=4,prefetch_read=8
 extra = {k: int(v) for k, v in extra.items()}
