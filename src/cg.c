@@ -16,7 +16,8 @@
  *                   call per step through the utils.h entry points
  *   CG_STRICT=1     dot products in the reference's exact summation order
  *                   (bit-identical results, slow)
- *   CG_SCHEDULE=classic|fused|fused_noq   kernel schedule of the solve path
+ *   CG_SCHEDULE=classic|fused|fused_noq|lean   kernel schedule of the solve path
+ *                   (default lean; fused in strict order, which needs q stored)
  *   CG_DUMP=prefix  write the final u as raw doubles to <prefix>.u.f64 (1 rank)
  *
  * Output on rank 0: the reference's two lines (cg.c:139-140) followed by one
@@ -160,13 +161,13 @@ int main(int argc, char **argv)
         cg_ctx *ctx = NULL;
         CK(cg_create(&ctx, device, n, row0, rows, rank, numprocs), "cg_create");
         const char *se = getenv("CG_SCHEDULE");
-        int sched = strict ? CG_SCHED_FUSED : CG_SCHED_FUSED_NOQ;
+        long sched = -1;                                               /* -1: the library picks */
         if (se && strcmp(se, "classic") == 0) sched = CG_SCHED_CLASSIC;
         else if (se && strcmp(se, "fused") == 0) sched = CG_SCHED_FUSED;
         else if (se && strcmp(se, "fused_noq") == 0) sched = CG_SCHED_FUSED_NOQ;
+        else if (se && strcmp(se, "lean") == 0) sched = CG_SCHED_LEAN;
         CK(cg_set_option(ctx, CG_OPT_REDUCE, strict ? CG_REDUCE_STRICT : CG_REDUCE_FAST), "cg_set_option(reduce)");
         CK(cg_set_option(ctx, CG_OPT_SCHEDULE, sched), "cg_set_option(schedule)");
-        bytes_per_point = sched == CG_SCHED_CLASSIC ? 88 : (sched == CG_SCHED_FUSED ? 80 : 64);
 #ifdef CG_USE_MPI
         if (numprocs > 1) {
             char id[128];
@@ -183,6 +184,8 @@ int main(int argc, char **argv)
         barrier();
         runtime = now_s() - t0;
         q1 = res.q1; q_init = res.q_init; done_iters = res.iters;
+        CK(cg_get_option(ctx, CG_OPT_SCHEDULE, &sched), "cg_get_option(schedule)");   /* the one that ran */
+        bytes_per_point = sched == CG_SCHED_CLASSIC ? 88 : sched == CG_SCHED_FUSED ? 80 : sched == CG_SCHED_FUSED_NOQ ? 64 : 56;
         const char *dump = getenv("CG_DUMP");
         if (dump && *dump && numprocs == 1) {
             double *h = (double *)malloc((size_t)count * sizeof(double));
