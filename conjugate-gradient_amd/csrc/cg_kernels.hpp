@@ -5,11 +5,16 @@
 // utils.c:373-379 compiled as C99 without FMA contraction), so must we.
 //
 // Kernel inventory (reference lines each one replaces):
-//   k_stencil          q = A d (+ optional fused d = beta*d - g, + d.q partials)
-//                      utils.c:15-35, utils.c:74-104, cg.c:81-87, utils.c:373-379
+//   k_stencil          the tiled kernel; its MODE selects what rides on the stencil walk:
+//                      0  q = A d, d.q partials                     utils.c:15-35, :74-104, :373-379
+//                      1  d' = beta*d - g first (stored), then as 0 cg.c:81-87
+//                      2  q recomputed, u += tau*d, g += tau*q, g.g partials      cg.c:63-76, :79
+//                      3  as 1 without storing d': a pure read pass (lean schedule)
+//                      4  d' again (stored), g' = g + tau*A d' (stored), g'.g' partials
+//                      5  as 4 plus u = (u + tau_prev*d) + tau*d' for two iterations at once
 //   k_update           u += tau*d ; g += tau*q ; g.g partials      cg.c:63-76,:79
-//   k_update_stencil   same, with q recomputed from d instead of loaded
 //   k_dupdate          d = beta*d - g                              cg.c:81-87
+//   k_uflush, k_umark  u updates the lean schedule still owes when a solve ends
 //   k_dot_partial      block partials of v.w                       utils.c:373-379
 //   k_dot_strict       v.w with ONE accumulator in index order     utils.c:373-379
 //   k_finish           fixed-order sum of block partials + the scalar recurrences
