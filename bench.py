@@ -37,9 +37,9 @@ def cpu_baseline(n, budget_s=40.0):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
     # the reference accepts perfect-square rank counts whose root divides the grid side (cg.c:15,23);
-    # the sample is sized for roughly 10-20 s of CPU work at the rates measured on such hosts
+    # the sample is sized for roughly 15-25 s of CPU work at the rates measured on such hosts
     for np_ in (64, 16, 4, 1):
-        iters = {64: 200, 16: 100, 4: 25, 1: 6}[np_]
+        iters = {64: 400, 16: 200, 4: 50, 1: 12}[np_]
         root = int(round(np_ ** 0.5))
         if np_ > cores or G % root:
             continue

@@ -639,11 +639,11 @@ __global__ __launch_bounds__(64) void k_dot_strict(const double *__restrict__ v,
 //   what 4: as 1, for an iteration whose u update is deferred (sc->u_applied stays)
 //   what 2: q0   = sum ; q_init = q0 ; stop = rtol^2*q0                (cg.c:55)
 //   what 3: dot  = sum                                                 (stand-alone dot)
-// With `strict_src` the sum is taken from *strict_src (k_dot_strict's result)
-// instead of the partials.  In a multi-rank solve the sum over ranks has been
-// formed before this kernel runs and arrives through `strict_src` as well.
+// With `strict_src` the sum is taken from there instead of the partials: one value
+// (the strict-order result), or `nsrc` per-rank sums of a multi-rank solve, which are
+// added here in rank order 0..nsrc-1 (step 5 of the fast order).
 __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long count,
-                                                   const double *strict_src, Scalars *sc, int what,
+                                                   const double *strict_src, int nsrc, Scalars *sc, int what,
                                                    double rtol, double *hist, long hist_cap)
 {
     if ((what < 2 || what == 4) && sc->done) return;
@@ -653,7 +653,10 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
         for (long k = threadIdx.x; k < count; k += kBlock) acc += partials[k];
     double s = block_sum(acc, wave_slots);
     if (threadIdx.x != 0) return;
-    if (strict_src != nullptr) s = *strict_src;
+    if (strict_src != nullptr) {
+        s = strict_src[0];
+        for (int r = 1; r < nsrc; ++r) s += strict_src[r];
+    }
     if (what == 0) {
         sc->dq = s;
         sc->tau = sc->q0 / s;
@@ -678,15 +681,6 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
     } else {
         sc->dot = s;
     }
-}
-
-// Sum of `count` per-rank values in rank order (multi-GPU step 5 of the order).
-__global__ void k_rank_sum(const double *vals, int count, double *out)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = vals[0];
-    for (int r = 1; r < count; ++r) s += vals[r];
-    *out = s;
 }
 
 // Fixed-order sum of block partials into one slot (local part of a multi-rank dot).

@@ -314,6 +314,7 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
     // sequential kernel from v and w; then runs the scalar recurrence `what`.
     hipStream_t s = c->stream;
     const double *src = nullptr;
+    int nsrc = 1;
     if (c->reduce == CG_REDUCE_STRICT) {
         // One accumulator over the whole grid in index order.  Row blocks are contiguous
         // in that order, so with several ranks the accumulator is handed from rank to rank:
@@ -337,10 +338,10 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
         hipLaunchKernelGGL(cg::k_partial_sum, dim3(1), dim3(kBlock), 0, s, partials, npart,
                            (what < 2 || what == 4) ? c->sc : nullptr, mine);
         CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
-        hipLaunchKernelGGL(cg::k_rank_sum, dim3(1), dim3(64), 0, s, c->comm->gather_buf(), c->nranks, c->strict_slot);
-        src = c->strict_slot;
+        src = c->comm->gather_buf();                       // added in rank order by k_finish
+        nsrc = c->nranks;
     }
-    hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, partials, npart, src, c->sc, what, rtol,
+    hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, partials, npart, src, nsrc, c->sc, what, rtol,
                        c->hist, c->hist_cap);
     return CG_OK;
 }
@@ -703,7 +704,7 @@ int cg_stencil(int device, long G, long row0, long rows, const double *d, const 
     HIPCHK(hipGetLastError());
     if (dq_host) {
         hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, sc->stream, sc->partials, t.ntiles,
-                           (const double *)nullptr, sc->sc, 3, 0.0, (double *)nullptr, 0L);
+                           (const double *)nullptr, 1, sc->sc, 3, 0.0, (double *)nullptr, 0L);
         HIPCHK(hipGetLastError());
         Scalars h;
         HIPCHK(hipMemcpyAsync(&h, sc->sc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
@@ -740,7 +741,7 @@ int cg_dot(int device, long count, const double *v, const double *w, int strict,
     else
         hipLaunchKernelGGL(cg::k_dot_partial<1>, dim3(fb), dim3(kBlock), 0, sc->stream, v, w, count, sc->partials);
     hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, sc->stream, sc->partials, (long)fb,
-                       (const double *)nullptr, sc->sc, 3, 0.0, (double *)nullptr, 0L);
+                       (const double *)nullptr, 1, sc->sc, 3, 0.0, (double *)nullptr, 0L);
     HIPCHK(hipGetLastError());
     Scalars h;
     HIPCHK(hipMemcpyAsync(&h, sc->sc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
