@@ -14,6 +14,13 @@
  * allocation, the three update loops, the scalar recurrences, the read-back --
  * sits behind this interface.  include/utils.h re-exports the reference's own
  * nine names on top of it.
+ *
+ * Threads: like the reference (one thread per rank, MPI_Init at cg.c:11) the
+ * library expects one calling thread per GPU.  The stand-alone operators of one
+ * device share that device's internal stream and scratch buffers, and a context
+ * is a single stream of work: calls on the same device or context from several
+ * threads at once must be serialised by the caller.  Different devices and
+ * different contexts are independent.
  */
 #ifndef CG_HIP_H
 #define CG_HIP_H
