@@ -683,6 +683,32 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
     }
 }
 
+// The c x c block at (r0, c0) of a row-major G-column array, copied to contiguous storage in
+// its own row-wise order: the local array of one rank of the reference's s x s decomposition
+// (utils.c:408-417), so that its sequential sum (utils.c:372-379) can be evaluated.
+__global__ __launch_bounds__(kBlock) void k_pack_block(const double *__restrict__ src, long G, long r0, long c0,
+                                                       long c, double *__restrict__ dst)
+{
+    const long total = c * c;
+    const long stride = (long)gridDim.x * kBlock;
+    for (long k = (long)blockIdx.x * kBlock + threadIdx.x; k < total; k += stride) {
+        const long i = k / c, j = k - i * c;
+        dst[k] = src[(r0 + i) * G + c0 + j];
+    }
+}
+
+// MPI_Allreduce of one double per rank as MPICH's recursive doubling forms it (utils.c:380):
+// partners at distance 1, 2, 4, ... -- a balanced binary tree over the ranks.  count is a power of two <= 64.
+__global__ void k_tree_sum(const double *vals, int count, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double part[64];
+    for (int r = 0; r < count; ++r) part[r] = vals[r];
+    for (int dist = 1; dist < count; dist *= 2)
+        for (int r = 0; r + dist < count; r += 2 * dist) part[r] = part[r] + part[r + dist];
+    *out = part[0];
+}
+
 // Fixed-order sum of block partials into one slot (local part of a multi-rank dot).
 __global__ __launch_bounds__(kBlock) void k_partial_sum(const double *partials, long count,
                                                         const Scalars *sc, double *out)

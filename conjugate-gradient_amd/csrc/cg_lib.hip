@@ -234,6 +234,10 @@ struct cg_ctx {
     double *strict_slot = nullptr;
     cg::exact::Workspace xs;              // strict order, parallel evaluation
     int strict_impl = kStrictAuto;
+    long strict_blocks = 0;               // s > 1: sum in the layout of the reference on s*s ranks
+    double *pack[2] = {nullptr, nullptr}; // one rank's block of v and w, contiguous
+    double *block_sums = nullptr;         // its s*s sequential sums
+    long pack_cap = 0;
     double *hist = nullptr;
     long hist_cap = 0;
     long hist_len = 0;
@@ -321,6 +325,27 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
         // in round k rank k continues from rank k-1's value, and an all-gather of one double
         // per rank publishes it.  The ranks take turns (this is the parity mode, not the
         // fast one); every rank ends with the same bits a single rank would compute.
+        if (c->strict_blocks > 1) {
+            // The reference's own multi-rank layout on this one GPU: rank r = ci*s + cj of its s x s
+            // decomposition sums the products of its (G/s)^2 block sequentially in local row-wise
+            // order (utils.c:372-379); MPI_Allreduce combines the sums (utils.c:380).
+            const long sdim = c->strict_blocks, cl = c->G / sdim, n2 = cl * cl;
+            const bool par = use_parallel_strict(c->strict_impl, n2);
+            const int pb = flat_blocks(n2, 0);
+            for (long r = 0; r < sdim * sdim; ++r) {
+                const long ci = r / sdim, cj = r % sdim;
+                hipLaunchKernelGGL(cg::k_pack_block, dim3(pb), dim3(kBlock), 0, s, v, c->G, ci * cl, cj * cl, cl, c->pack[0]);
+                if (w != v) hipLaunchKernelGGL(cg::k_pack_block, dim3(pb), dim3(kBlock), 0, s, w, c->G, ci * cl, cj * cl, cl, c->pack[1]);
+                const double *pv = c->pack[0], *pw = (w != v) ? c->pack[1] : c->pack[0];
+                if (par) cg::exact::enqueue(s, c->xs, pv, pw, n2, 0.0, c->block_sums + r);
+                else hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, pv, pw, n2, 0.0, nullptr, c->block_sums + r);
+            }
+            hipLaunchKernelGGL(cg::k_tree_sum, dim3(1), dim3(1), 0, s, c->block_sums, (int)(sdim * sdim), c->strict_slot);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, partials, npart, c->strict_slot, 1, c->sc, what, rtol,
+                               c->hist, c->hist_cap);
+            return CG_OK;
+        }
         const bool par = use_parallel_strict(c->strict_impl, c->count);
         for (int k = 0; k < c->nranks; ++k) {
             double *slot = c->nranks > 1 ? c->comm->gather_buf() + c->rank : c->strict_slot;
@@ -860,6 +885,7 @@ int cg_destroy(cg_ctx *c)
     c->xs.release();
     (void)hipFree(c->u_alloc); (void)hipFree(c->g_alloc[0]); (void)hipFree(c->g_alloc[1]); (void)hipFree(c->q_alloc);
     for (double *p : c->d_alloc) (void)hipFree(p);
+    (void)hipFree(c->pack[0]); (void)hipFree(c->pack[1]); (void)hipFree(c->block_sums);
     (void)hipFree(c->partials); (void)hipFree(c->strict_slot); (void)hipFree(c->sc); (void)hipFree(c->hist);
     if (c->host_sc) (void)hipHostFree(c->host_sc);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -899,6 +925,10 @@ int cg_set_option(cg_ctx *c, int key, long value)
     case CG_OPT_TILE_WGS:
         if (value < 0) return fail(CG_ERR_ARG, "workgroup cap must be >= 0");
         c->tile_wgs = value; break;
+    case CG_OPT_STRICT_BLOCKS:
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(CG_ERR_ARG, "rank-grid side must be 0/1 (off), 2, 4 or 8");
+        c->strict_blocks = value; break;
     case CG_OPT_STRICT_IMPL:
         if (value < kStrictAuto || value > kStrictParallel) return fail(CG_ERR_ARG, "strict implementation must be 1, 2 or 3");
         c->strict_impl = (int)value; break;
@@ -921,6 +951,7 @@ int cg_get_option(cg_ctx *c, int key, long *value)
     case CG_OPT_PREFETCH: *value = c->prefetch; break;
     case CG_OPT_PREFETCH_READ: *value = ctx_geom(c).pf_mode[3]; break;
     case CG_OPT_STRICT_IMPL: *value = c->strict_impl; break;
+    case CG_OPT_STRICT_BLOCKS: *value = c->strict_blocks; break;
     case CG_OPT_TILE_WGS: *value = ctx_geom(c).max_wgs; break;
     default: return fail(CG_ERR_ARG, "unknown option key %d", key);
     }
@@ -966,6 +997,22 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     const int sched = c->effective_schedule();
     hipStream_t s = c->stream;
 
+    if (c->reduce == CG_REDUCE_STRICT && c->strict_blocks > 1) {
+        const long sdim = c->strict_blocks;
+        if (c->nranks != 1) return fail(CG_ERR_STATE, "the reference's multi-rank summation layout is emulated on one GPU only");
+        if (c->G % sdim != 0)
+            return fail(CG_ERR_ARG, "grid side %ld not divisible by %ld (the reference has the same rule, cg.c:23-26)", c->G, sdim);
+        const long n2 = (c->G / sdim) * (c->G / sdim);
+        if (c->pack_cap < n2) {
+            drop_graph(c);
+            (void)hipFree(c->pack[0]); (void)hipFree(c->pack[1]); (void)hipFree(c->block_sums);
+            c->pack[0] = c->pack[1] = c->block_sums = nullptr; c->pack_cap = 0;
+            HIPCHK(hipMalloc(&c->pack[0], (size_t)n2 * sizeof(double)));
+            HIPCHK(hipMalloc(&c->pack[1], (size_t)n2 * sizeof(double)));
+            HIPCHK(hipMalloc(&c->block_sums, 64 * sizeof(double)));
+            c->pack_cap = n2;
+        }
+    }
     if (c->reduce == CG_REDUCE_STRICT && use_parallel_strict(c->strict_impl, c->count)) {
         const long before = c->xs.cap_chunks;
         HIPCHK(c->xs.reserve(c->count));

@@ -18,6 +18,7 @@ OPT_REDUCE, OPT_SCHEDULE, OPT_TILE_H, OPT_GRAPH_ITERS, OPT_XCD_REMAP, OPT_FLAT_B
 OPT_STRICT_IMPL = 8
 OPT_TILE_WGS = 9
 OPT_PREFETCH_READ = 11
+OPT_STRICT_BLOCKS = 12
 STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL = 1, 2, 3
 VEC_U, VEC_G, VEC_D, VEC_Q = 0, 1, 2, 3
 

@@ -124,7 +124,7 @@ class CGSolver:
         _l.check(self._lib.cg_set_option(self._ctx, key, int(value)))
 
     def configure(self, reduce=None, schedule=None, tile_h=None, graph_iters=None, xcd_remap=None,
-                  flat_blocks=None, prefetch=None, strict_impl=None, tile_wgs=None, prefetch_read=None):
+                  flat_blocks=None, prefetch=None, strict_impl=None, tile_wgs=None, prefetch_read=None, strict_blocks=None):
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
@@ -147,6 +147,8 @@ class CGSolver:
             self.set_option(_l.OPT_STRICT_IMPL, strict_impl)
         if tile_wgs is not None:
             self.set_option(_l.OPT_TILE_WGS, tile_wgs)
+        if strict_blocks is not None:
+            self.set_option(_l.OPT_STRICT_BLOCKS, strict_blocks)
         if prefetch_read is not None:
             self.set_option(_l.OPT_PREFETCH_READ, prefetch_read)
         return self

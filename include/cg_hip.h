@@ -110,6 +110,12 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_STRICT_IMPL 8   /* how the strict order is evaluated: 1 = auto (default), 2 = literal
                                   one-accumulator replay, 3 = parallel evaluation (same bits, see cg_dot) */
 #define CG_OPT_PREFETCH_READ 11 /* same for LEAN's read-only pass alone; 0 = default (8) */
+#define CG_OPT_STRICT_BLOCKS 12 /* with CG_REDUCE_STRICT on one GPU: s = 2, 4 or 8 sums every dot product in the
+                                  layout of the reference run on s*s MPI ranks -- each rank's (G/s)^2 block
+                                  sequentially in its local row-wise order (utils.c:372-379, blocks as in
+                                  utils.c:408-417), the s*s sums combined as MPICH's MPI_Allreduce combines
+                                  them (utils.c:380) -- and so reproduces the bits of `mpirun -np s*s ./cg`.
+                                  0 or 1 = the single-rank order (default) */
 #define CG_OPT_TILE_WGS    9   /* cap on workgroups per tiled launch; with more tiles than that each
                                   workgroup walks several tiles in turn.  0 = auto (256 with automatic
                                   tile height, one workgroup per tile with an explicit CG_OPT_TILE_H) */

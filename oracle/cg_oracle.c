@@ -195,3 +195,65 @@ long oracle_cg_rowblocks(long n, long nblocks, long max_iters, double rtol,
     free(halo_bot);
     return it;
 }
+
+/* The dot product as the reference forms it on P = s*s ranks (utils.c:368-381 on the
+ * s x s cartesian layout of utils.c:408-417): rank r = ci*s + cj holds the c x c block
+ * (c = G/s) of rows ci*c.. and columns cj*c.., stored row-wise, and sums ITS products with
+ * one accumulator in its local storage order; MPI_Allreduce then combines the P sums.
+ * MPICH 3.3.2, one double, power-of-two rank counts: recursive doubling, i.e. partners at
+ * distance 1, 2, 4, ... -- a balanced binary tree over the ranks, the same value on every
+ * rank.  (Checked against the reference's own np = 4 and np = 16 outputs: bit-identical.) */
+double oracle_dot_blocks2d(long G, long s, const double *v, const double *w)
+{
+    const long c = G / s, P = s * s;
+    double part[64];
+    if (P > 64 || G % s != 0) return 0.0 / 0.0;
+    for (long r = 0; r < P; ++r) {
+        const long ci = r / s, cj = r % s;
+        double acc = 0.0;
+        for (long i = 0; i < c; ++i) {
+            const double *pv = v + (ci * c + i) * G + cj * c, *pw = w + (ci * c + i) * G + cj * c;
+            for (long j = 0; j < c; ++j) {
+                const double t = pv[j] * pw[j];
+                acc = acc + t;
+            }
+        }
+        part[r] = acc;
+    }
+    for (long dist = 1; dist < P; dist *= 2)
+        for (long r = 0; r + dist < P; r += 2 * dist) part[r] = part[r] + part[r + dist];
+    return part[0];
+}
+
+/* The reference's np = s*s solve (cg.c:95-129).  The stencil, halo handling and the three
+ * update loops produce, element by element, what the single-rank loop produces; what the
+ * decomposition changes is the summation layout of the three dot products. */
+long oracle_cg_blocks2d(long n, long s, long max_iters, double rtol,
+                        double *u, double *g, double *d, double *q,
+                        double *q1_hist, double *q_init)
+{
+    const long G = n + 1;
+    const long N = G * G;
+    if (s < 1 || s * s > 64 || G % s != 0 || ((s * s) & (s * s - 1)) != 0) return -1;
+    oracle_init_d(n, 0, G, d);
+    oracle_init_g(N, d, g);
+    memset(u, 0, (size_t)N * sizeof(double));
+    memset(q, 0, (size_t)N * sizeof(double));
+    double q0 = oracle_dot_blocks2d(G, s, g, g);                      /* cg.c:55 */
+    if (q_init) *q_init = q0;
+    const double stop = rtol * rtol * q0;
+    long it = 0;
+    for (; it < max_iters; ++it) {
+        oracle_stencil(G, 0, G, d, NULL, NULL, q);                    /* cg.c:97 */
+        const double tau = q0 / oracle_dot_blocks2d(G, s, d, q);      /* cg.c:100-101 */
+        oracle_axpy(N, tau, d, u);                                    /* cg.c:102-108 */
+        oracle_axpy(N, tau, q, g);                                    /* cg.c:109-115 */
+        const double q1 = oracle_dot_blocks2d(G, s, g, g);            /* cg.c:118 */
+        const double beta = q1 / q0;                                  /* cg.c:119 */
+        oracle_xpay(N, beta, d, g);                                   /* cg.c:120-126 */
+        q0 = q1;                                                      /* cg.c:128 */
+        if (q1_hist) q1_hist[it] = q1;
+        if (rtol > 0 && q1 <= stop) { ++it; break; }
+    }
+    return it;
+}

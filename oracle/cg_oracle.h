@@ -76,4 +76,14 @@ long oracle_cg_rowblocks(long n, long nblocks, long max_iters, double rtol,
 #ifdef __cplusplus
 }
 #endif
+/* Dot product and solve in the summation layout of the reference's own multi-rank runs:
+ * s x s blocks of (G/s)^2 points, each summed sequentially in its local row-wise order
+ * (utils.c:368-379), the s*s sums combined pairwise at distances 1, 2, 4, ... (the
+ * MPI_Allreduce of utils.c:380 under MPICH's recursive doubling).  s*s must be a power of
+ * two <= 64 and s must divide G.  Pinned by the reference's np = 4 and np = 16 outputs. */
+double oracle_dot_blocks2d(long G, long s, const double *v, const double *w);
+long oracle_cg_blocks2d(long n, long s, long max_iters, double rtol,
+                        double *u, double *g, double *d, double *q,
+                        double *q1_hist, double *q_init);
+
 #endif

@@ -43,6 +43,10 @@ def load():
         lib.oracle_cg.argtypes = [C.c_long, C.c_long, C.c_double, _dp, _dp, _dp, _dp, C.c_void_p, C.c_void_p]
         lib.oracle_cg_rowblocks.argtypes = [C.c_long, C.c_long, C.c_long, C.c_double, _dp, _dp, _dp, _dp,
                                             C.c_void_p, C.c_void_p]
+        lib.oracle_dot_blocks2d.argtypes = [C.c_long, C.c_long, _dp, _dp]
+        lib.oracle_dot_blocks2d.restype = C.c_double
+        lib.oracle_cg_blocks2d.argtypes = lib.oracle_cg_rowblocks.argtypes
+        lib.oracle_cg_blocks2d.restype = C.c_long
         _lib = lib
     return _lib
 
@@ -87,17 +91,27 @@ def xpay(b, d, g):
     load().oracle_xpay(d.size, b, d, g)
 
 
-def cg(n, max_iters, rtol=0.0, nblocks=None):
-    """Returns dict(iters, q1, q_init, u, g, d, q, hist)."""
+def dot_blocks2d(v, w, s):
+    """v.w in the summation layout of the reference on s*s ranks (v, w: G x G arrays)."""
+    return load().oracle_dot_blocks2d(v.shape[0], s, np.ascontiguousarray(v), np.ascontiguousarray(w))
+
+
+def cg(n, max_iters, rtol=0.0, nblocks=None, blocks2d=None):
+    """Returns dict(iters, q1, q_init, u, g, d, q, hist).
+
+    nblocks: row blocks with chained sums (single-rank bits); blocks2d = s: the reference's
+    own s*s-rank summation layout."""
     G = n + 1
     u, g, d, q = (np.empty((G, G)) for _ in range(4))
     hist = np.zeros(max(max_iters, 1))
     qi = C.c_double(0.0)
-    if nblocks is None:
+    if blocks2d is not None:
+        it = load().oracle_cg_blocks2d(n, blocks2d, max_iters, rtol, u, g, d, q, _opt(hist), C.addressof(qi))
+    elif nblocks is None:
         it = load().oracle_cg(n, max_iters, rtol, u, g, d, q, _opt(hist), C.addressof(qi))
     else:
         it = load().oracle_cg_rowblocks(n, nblocks, max_iters, rtol, u, g, d, q, _opt(hist), C.addressof(qi))
     if it < 0:
-        raise ValueError("oracle_cg_rowblocks: grid side not divisible by the block count")
+        raise ValueError("oracle: grid side not divisible by the block count (or unsupported rank count)")
     return dict(iters=it, q1=hist[it - 1] if it > 0 else qi.value, q_init=qi.value, u=u, g=g, d=d, q=q,
                 hist=hist[:it].copy())

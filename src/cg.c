@@ -15,7 +15,9 @@
  *   CG_PATH=calls   the reference's own loop structure (cg.c:53-130), one library
  *                   call per step through the utils.h entry points
  *   CG_STRICT=1     dot products in the reference's exact summation order
- *                   (bit-identical results, slow)
+ *                   (bit-identical results, about a third of the fast rate)
+ *   CG_STRICT_NP=P  with CG_STRICT=1 on one GPU: the summation layout of the reference run
+ *                   on P = 4, 16 or 64 ranks, i.e. the bits of `mpirun -np P ./cg n`
  *   CG_SCHEDULE=classic|fused|fused_noq|lean   kernel schedule of the solve path
  *                   (default lean; fused in strict order, which needs q stored)
  *   CG_DUMP=prefix  write the final u as raw doubles to <prefix>.u.f64 (1 rank)
@@ -168,6 +170,12 @@ int main(int argc, char **argv)
         else if (se && strcmp(se, "lean") == 0) sched = CG_SCHED_LEAN;
         CK(cg_set_option(ctx, CG_OPT_REDUCE, strict ? CG_REDUCE_STRICT : CG_REDUCE_FAST), "cg_set_option(reduce)");
         CK(cg_set_option(ctx, CG_OPT_SCHEDULE, sched), "cg_set_option(schedule)");
+        const char *snp = getenv("CG_STRICT_NP");
+        if (strict && snp && *snp) {
+            const int p = atoi(snp), side = (int)(sqrt((double)p) + 0.5);
+            if (side * side != p) { if (rank == 0) printf("[ERROR] Number of processors must be a perfect square.\n"); return 1; }   /* cg.c:15-18 */
+            CK(cg_set_option(ctx, CG_OPT_STRICT_BLOCKS, side), "cg_set_option(strict blocks)");
+        }
 #ifdef CG_USE_MPI
         if (numprocs > 1) {
             char id[128];

@@ -161,3 +161,34 @@ def test_headline_16384_1000_strict_is_bit_identical_to_the_reference(cg, oracle
     assert float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex()
     assert float(seq_sum(oracle, s.vector(cg.VEC_U))).hex() == rec["sum_u_hex"]
     print(f"strict 16384^2 x 1000 iterations: {r.seconds:.2f} s = {1000 / r.seconds:.1f} it/s")
+
+
+# ------------------------------------- the reference's own multi-rank results ------
+
+@pytest.mark.parametrize("impl", ["replay", "parallel"])
+@pytest.mark.parametrize("n,iters,np_", [(15, 10, 4), (63, 50, 4), (63, 50, 16), (255, 200, 4), (255, 200, 16), (1023, 200, 4)])
+def test_reference_multirank_summation_layout_reproduces_its_np_outputs(cg, golden, n, iters, np_, impl):
+    # `mpirun -np 4|16 ./cg n`: each rank sums its 2-D block sequentially, MPI_Allreduce combines the sums.
+    # One GPU evaluating the dot products in that layout gives the reference's multi-rank bits.
+    rec = golden[(n, iters, np_, 0.0)]
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_blocks=int(round(np_ ** 0.5)),
+                                 strict_impl=cg.STRICT_REPLAY if impl == "replay" else cg.STRICT_PARALLEL).init_problem()
+    r = s.solve(iters)
+    assert r.iters == iters
+    assert float(r.q_init).hex() == float.fromhex(rec["q_init_hex"]).hex()
+    assert float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex()
+
+
+def test_config_4096_to_1e8_is_bit_identical_to_the_reference_on_4_ranks(cg, golden):
+    # BASELINE.json configs[1]: 4096^2 to a relative residual of 1e-8.  The reference was run on 4 ranks
+    # (a single rank would take hours): 6937 iterations.  Same summation layout here: same stopping
+    # iteration, same last q1, bit for bit.
+    rec = golden.get((4095, 100000, 4, 1e-8))
+    if rec is None:
+        pytest.skip("golden not generated")
+    s = cg.CGSolver(4095).configure(reduce=cg.REDUCE_STRICT, strict_blocks=2).init_problem()
+    r = s.solve(100000, rtol=1e-8)
+    assert r.converged and r.iters == rec["iters"] == 6937
+    assert float(r.q_init).hex() == float.fromhex(rec["q_init_hex"]).hex()
+    assert float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex()
+    print(f"4096^2 to 1e-8 in the reference's np=4 order: {r.iters} iterations in {r.seconds:.2f} s")

@@ -111,3 +111,14 @@ def test_chunked_first_iteration_equals_whole_grid_oracle(oracle, n, chunk):
         assert np.array_equal(u1.view(np.uint64), ref["u"][i].view(np.uint64))
         assert np.array_equal(g1.view(np.uint64), ref["g"][i].view(np.uint64))
         assert np.array_equal(d1.view(np.uint64), ref["d"][i].view(np.uint64))
+
+
+@pytest.mark.parametrize("n,iters,np_", [(15, 10, 4), (63, 50, 4), (63, 50, 16), (255, 200, 4), (255, 200, 16), (1023, 200, 4)])
+def test_oracle_in_the_references_multirank_summation_layout_matches_its_np_outputs(oracle, golden, n, iters, np_):
+    # the reference run on 4 and 16 ranks (tests/golden/make_golden.py): per-block sequential sums, then
+    # MPI_Allreduce; the restatement of that layout reproduces every bit of q1 and q_init
+    rec = golden[(n, iters, np_, 0.0)]
+    res = oracle.cg(n, iters, blocks2d=int(round(np_ ** 0.5)))
+    assert res["iters"] == iters
+    assert float(res["q1"]).hex() == float.fromhex(rec["q1_hex"]).hex()
+    assert float(res["q_init"]).hex() == float.fromhex(rec["q_init_hex"]).hex()
