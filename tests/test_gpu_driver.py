@@ -92,3 +92,13 @@ def test_row_blocks_over_mpi_ranks_fast_order(golden):
     _, m = run(["255"], env={"CG_PATH": "calls"}, mpi=2)
     q1_ref = float.fromhex(rec["q1_hex"])
     assert abs(float(m.group(1)) - q1_ref) <= 5e-8 * q1_ref
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+@pytest.mark.parametrize("np_", [4, 16])
+def test_driver_reproduces_the_references_multirank_output(golden, np_):
+    # what `mpirun -np 4|16 ./cg 255` of the reference prints, from one GPU
+    rec = golden[(255, 200, np_, 0.0)]
+    lines, m = run(["255"], env={"CG_STRICT": "1", "CG_STRICT_NP": str(np_)})
+    assert m.group(2) == rec["q1_hex"]
+    assert lines[0] == "[INFO] norm_g^2 = %.16f" % float.fromhex(rec["q1_hex"])
