@@ -108,6 +108,12 @@ __device__ __forceinline__ long xcd_remap(long b, long ntiles)
 
 // ------------------------------------------------------------------- stencil --
 
+// Coefficients of the five points the reference's kernels read (entries 1, 3, 4, 5, 7 of its
+// 3x3 integer array, cg.c:33), converted to double as utils.c:27-31 converts them per use.
+struct Coef5 {
+    double up, left, centre, right, down;
+};
+
 struct StencilArgs {
     const double *d_in;               // rows x G block of the direction vector
     const double *g;                  // rows x G block of the gradient (fused d-update)
@@ -132,6 +138,7 @@ struct StencilArgs {
     int rt_total;                     // row tiles in the whole block
     int edge_pair;                    // 1 = this launch covers row tiles 0 and rt_total-1 only
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
+    Coef5 coef;                       // stencil coefficients
 };
 
 // Streaming accesses carry the non-temporal hint (global_load/store ... nt): every
@@ -162,15 +169,15 @@ template <> struct Pack<2> {
 
 // The five-point sum in the reference's order: up, left, centre, right, down,
 // added one by one to a zero accumulator (utils.c:25-31).
-__device__ __forceinline__ double five_point(double up, double left, double centre,
+__device__ __forceinline__ double five_point(const Coef5 &c, double up, double left, double centre,
                                              double right, double down)
 {
     double acc = 0.0;
-    acc += -1.0 * up;
-    acc += -1.0 * left;
-    acc += 4.0 * centre;
-    acc += -1.0 * right;
-    acc += -1.0 * down;
+    acc += c.up * up;
+    acc += c.left * left;
+    acc += c.centre * centre;
+    acc += c.right * right;
+    acc += c.down * down;
     return acc;
 }
 
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 const double left = (v == 0) ? midL : mid[v - 1];
                 const double right = (v == VEC - 1) ? midR : mid[v + 1];
                 const bool in = row_in && (j + v >= 1) && (j + v <= G - 2);
-                qv[v] = in ? five_point(up[v], left, mid[v], right, cur[v]) : 0.0;
+                qv[v] = in ? five_point(a.coef, up[v], left, mid[v], right, cur[v]) : 0.0;
             }
             if (MODE == 2) {
                 double pu[VEC], pg[VEC];

@@ -49,6 +49,16 @@ using cg::kBlock;
 using cg::Scalars;
 using cg::StencilArgs;
 
+// cg.c:33's coefficients at the five points the reference's kernels read.
+constexpr cg::Coef5 kPoisson5 = {-1.0, -1.0, 4.0, -1.0, -1.0};
+
+// Entries 1, 3, 4, 5, 7 of a 3x3 integer coefficient array (row-wise, as the reference's
+// stencil_struct holds it); entries 0, 2, 6, 8 are never read by the reference (utils.c:27-31).
+cg::Coef5 coef_from9(const int *s9)
+{
+    return cg::Coef5{(double)s9[1], (double)s9[3], (double)s9[4], (double)s9[5], (double)s9[7]};
+}
+
 constexpr int kMaxFlatBlocks = 512;       // two workgroups per CU: best measured HBM efficiency for mixed streams
 constexpr int kMaxDevices = 64;
 
@@ -233,6 +243,7 @@ struct cg_ctx {
     Scalars *sc = nullptr;
     double *strict_slot = nullptr;
     cg::exact::Workspace xs;              // strict order, parallel evaluation
+    cg::Coef5 coef = kPoisson5;           // stencil coefficients (cg_set_stencil)
     int strict_impl = kStrictAuto;
     long strict_blocks = 0;               // s > 1: sum in the layout of the reference on s*s ranks
     double *pack[2] = {nullptr, nullptr}; // one rank's block of v and w, contiguous
@@ -376,6 +387,7 @@ StencilArgs base_args(cg_ctx *c, const TileGeom &t)
     StencilArgs a;
     memset(&a, 0, sizeof a);
     a.sc = c->sc;
+    a.coef = c->coef;
     a.G = c->G; a.rows = c->rows; a.row0 = c->row0;
     a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = c->remap;
     a.rt_first = 0; a.rt_total = (int)(t.ntiles / t.nstrips); a.edge_pair = 0;
@@ -710,6 +722,14 @@ int cg_init_g(int device, long count, const double *d, double *g)
 int cg_stencil(int device, long G, long row0, long rows, const double *d, const double *top,
                const double *bot, double *q, double *dq_host)
 {
+    static const int poisson9[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};      // cg.c:33
+    return cg_stencil9(device, poisson9, G, row0, rows, d, top, bot, q, dq_host);
+}
+
+int cg_stencil9(int device, const int *stencil9, long G, long row0, long rows, const double *d, const double *top,
+                const double *bot, double *q, double *dq_host)
+{
+    if (!stencil9) return fail(CG_ERR_ARG, "cg_stencil9: coefficient array is NULL");
     if (!d || !q || G < 3 || rows < 1 || row0 < 0 || row0 + rows > G)
         return fail(CG_ERR_ARG, "cg_stencil: need G >= 3 and 0 <= row0 < row0+rows <= G");
     if ((row0 > 0 && !top) || (row0 + rows < G && !bot))
@@ -723,6 +743,7 @@ int cg_stencil(int device, long G, long row0, long rows, const double *d, const 
     memset(&a, 0, sizeof a);
     a.d_in = d; a.d_top = row0 > 0 ? top : nullptr; a.d_bot = row0 + rows < G ? bot : nullptr;
     a.q = q; a.partials = sc->partials; a.sc = nullptr;
+    a.coef = coef_from9(stencil9);
     a.G = G; a.rows = rows; a.row0 = row0; a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = 1;
     a.rt_first = 0; a.rt_total = (int)(t.ntiles / t.nstrips); a.edge_pair = 0;
     launch_stencil<0, true>(t, a, sc->stream);
@@ -935,6 +956,14 @@ int cg_set_option(cg_ctx *c, int key, long value)
     default: return fail(CG_ERR_ARG, "unknown option key %d", key);
     }
     drop_graph(c);
+    return CG_OK;
+}
+
+int cg_set_stencil(cg_ctx *c, const int *stencil9)
+{
+    if (!c || !stencil9) return fail(CG_ERR_ARG, "cg_set_stencil: NULL argument");
+    c->coef = coef_from9(stencil9);
+    drop_graph(c);                                      // captured launches hold the old coefficients
     return CG_OK;
 }
 

@@ -53,12 +53,15 @@ SIGNATURES = {
     "cg_init_g": (C.c_int, [C.c_int, C.c_long, C.c_void_p, C.c_void_p]),
     "cg_stencil": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, _dp]),
+    "cg_stencil9": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, _dp]),
     "cg_dot": (C.c_int, [C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_double, _dp]),
     "cg_axpy": (C.c_int, [C.c_int, C.c_long, C.c_double, C.c_void_p, C.c_void_p]),
     "cg_xpay": (C.c_int, [C.c_int, C.c_long, C.c_double, C.c_void_p, C.c_void_p]),
     "cg_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int]),
     "cg_destroy": (C.c_int, [C.c_void_p]),
     "cg_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_long]),
+    "cg_set_stencil": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cg_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long)]),
     "cg_init_problem": (C.c_int, [C.c_void_p]),
     "cg_solve": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.POINTER(Result)]),

@@ -75,11 +75,21 @@ def init_g(count, d, g, device=0):
     _l.check(_l.load().cg_init_g(device, count, _p(d), _p(g)))
 
 
-def stencil(G, row0, rows, d, q, top=None, bot=None, device=0, want_dq=False):
+def _stencil9(coef5):
+    """(up, left, centre, right, down) -> the 3x3 row-wise integer array of a stencil_struct (cg.c:33)."""
+    up, left, centre, right, down = (int(x) for x in coef5)
+    return (C.c_int * 9)(0, up, 0, left, centre, right, 0, down, 0)
+
+
+def stencil(G, row0, rows, d, q, top=None, bot=None, device=0, want_dq=False, coef5=None):
     """q = A d on a row block: apply_stencil_serial / the row part of apply_stencil_parallel."""
     dq = C.c_double(0.0)
-    _l.check(_l.load().cg_stencil(device, G, row0, rows, _p(d), _p(top), _p(bot), _p(q),
-                                  C.byref(dq) if want_dq else None))
+    if coef5 is None:
+        _l.check(_l.load().cg_stencil(device, G, row0, rows, _p(d), _p(top), _p(bot), _p(q),
+                                      C.byref(dq) if want_dq else None))
+    else:
+        _l.check(_l.load().cg_stencil9(device, _stencil9(coef5), G, row0, rows, _p(d), _p(top), _p(bot), _p(q),
+                                       C.byref(dq) if want_dq else None))
     return dq.value if want_dq else None
 
 
@@ -151,6 +161,11 @@ class CGSolver:
             self.set_option(_l.OPT_STRICT_BLOCKS, strict_blocks)
         if prefetch_read is not None:
             self.set_option(_l.OPT_PREFETCH_READ, prefetch_read)
+        return self
+
+    def set_stencil(self, coef5):
+        """Coefficients (up, left, centre, right, down): entries 1, 3, 4, 5, 7 of the reference's array."""
+        _l.check(self._lib.cg_set_stencil(self._ctx, _stencil9(coef5)))
         return self
 
     def get_option(self, key):

@@ -64,6 +64,11 @@ int cg_init_g(int device, long count, const double *d, double *g);
  * returns d.q accumulated in the fast order (fused, one pass).               */
 int cg_stencil(int device, long G, long row0, long rows, const double *d,
                const double *top, const double *bot, double *q, double *dq_host);
+/* The same with the coefficients of a stencil_struct (utils.h:3-7): stencil9 is the 3x3 integer
+ * array, row-wise (host pointer).  As in the reference only entries 1, 3, 4, 5, 7 -- up, left,
+ * centre, right, down -- are read (utils.c:27-31); cg_stencil uses cg.c:33's {0,-1,0,-1,4,-1,0,-1,0}. */
+int cg_stencil9(int device, const int *stencil9, long G, long row0, long rows, const double *d,
+                const double *top, const double *bot, double *q, double *dq_host);
 /* *result_host = sum v[k]*w[k], k = 0..count-1.  strict != 0: one accumulator in
  * index order starting from `start` (bit-identical to utils.c:372-379);
  * strict = 0: the documented fast order (start is added last).
@@ -125,6 +130,9 @@ typedef struct cg_ctx cg_ctx;
 int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks);
 int cg_destroy(cg_ctx *ctx);
 int cg_set_option(cg_ctx *ctx, int key, long value);
+/* Coefficients of the context's stencil: the 3x3 integer array of a stencil_struct (cg.c:33-38),
+ * of which entries 1, 3, 4, 5, 7 are used, as in utils.c:27-31.  Default: cg.c:33's values. */
+int cg_set_stencil(cg_ctx *ctx, const int *stencil9);
 /* Current value of an option; for CG_OPT_SCHEDULE, CG_OPT_TILE_H, CG_OPT_TILE_WGS and
  * CG_OPT_U_DEFER the value in effect after automatic selection. */
 int cg_get_option(cg_ctx *ctx, int key, long *value);

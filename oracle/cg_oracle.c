@@ -40,18 +40,27 @@ void oracle_init_g(long count, const double *d, double *g)
     for (long k = 0; k < count; ++k) g[k] = -d[k];
 }
 
+/* Entries 1, 3, 4, 5, 7 of the reference's 3x3 integer coefficient array (cg.c:33: up, left,
+ * centre, right, down); the other four are never read by its kernels (utils.c:27-31). */
+static int coef_up = -1, coef_left = -1, coef_centre = 4, coef_right = -1, coef_down = -1;
+
+void oracle_set_stencil(const int c5[5])
+{
+    coef_up = c5[0]; coef_left = c5[1]; coef_centre = c5[2]; coef_right = c5[3]; coef_down = c5[4];
+}
+
 /* One stencil point; the five terms are added to a zero-initialised
  * accumulator in the order up, left, centre, right, down (utils.c:25-31).
- * The integer coefficients -1 and 4 are converted to double per use. */
+ * The integer coefficients are converted to double per use. */
 static inline double stencil_point(double up, double left, double centre,
                                    double right, double down)
 {
     double acc = 0;
-    acc += (double)(-1) * up;
-    acc += (double)(-1) * left;
-    acc += (double)(4) * centre;
-    acc += (double)(-1) * right;
-    acc += (double)(-1) * down;
+    acc += (double)coef_up * up;
+    acc += (double)coef_left * left;
+    acc += (double)coef_centre * centre;
+    acc += (double)coef_right * right;
+    acc += (double)coef_down * down;
     return acc;
 }
 

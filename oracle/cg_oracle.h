@@ -86,4 +86,8 @@ long oracle_cg_blocks2d(long n, long s, long max_iters, double rtol,
                         double *u, double *g, double *d, double *q,
                         double *q1_hist, double *q_init);
 
+/* Coefficients used by every stencil evaluation from now on: up, left, centre, right, down
+ * (entries 1, 3, 4, 5, 7 of cg.c:33's array).  Process-wide; default -1, -1, 4, -1, -1. */
+void oracle_set_stencil(const int c5[5]);
+
 #endif

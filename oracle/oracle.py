@@ -55,6 +55,14 @@ def _opt(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+DEFAULT_STENCIL = (-1, -1, 4, -1, -1)
+
+
+def set_stencil(c5=DEFAULT_STENCIL):
+    """Coefficients (up, left, centre, right, down) of every later stencil evaluation; process-wide."""
+    load().oracle_set_stencil((C.c_int * 5)(*[int(x) for x in c5]))
+
+
 def init_d(n, row0=0, rows=None):
     G = n + 1
     rows = G if rows is None else rows

@@ -10,8 +10,12 @@
  *   `iter<200;`       -> `iter<ref_max_iters;`          run-time iteration count
  *   `q0 = q1;`        -> `q0 = q1; if (ref_should_stop(q1, iter)) break;`
  *   `free(localu);`   -> `ref_final(...); free(localu);` full-precision report
+ *   `memcpy(stencil->stencil, my_stencil, sizeof(my_stencil));`
+ *                     -> the same followed by `ref_stencil(stencil->stencil);`
  * Environment: REF_ITERS (default 200), REF_RTOL (default 0 = never stop
- * early), REF_DUMP (prefix for raw u/g/d dumps, rank 0 of a 1-rank run only).
+ * early), REF_DUMP (prefix for raw u/g/d dumps, rank 0 of a 1-rank run only),
+ * REF_STENCIL="up,left,centre,right,down" (the five entries of the 3x3 coefficient
+ * array that the reference's kernels read, utils.c:27-31; default: cg.c:33's own).
  */
 #include <math.h>
 #include <stdio.h>
@@ -28,6 +32,16 @@ __attribute__((constructor)) static void ref_hook_init(void)
     if (s && *s) ref_max_iters = atoi(s);
     s = getenv("REF_RTOL");
     if (s && *s) ref_rtol = atof(s);
+}
+
+/* Overrides entries 1, 3, 4, 5, 7 of the 3x3 coefficient array from REF_STENCIL. */
+void ref_stencil(int *stencil9)
+{
+    const char *s = getenv("REF_STENCIL");
+    int v[5];
+    if (s && *s && sscanf(s, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5) {
+        stencil9[1] = v[0]; stencil9[3] = v[1]; stencil9[4] = v[2]; stencil9[5] = v[3]; stencil9[7] = v[4];
+    }
 }
 
 /* Called after q0 = q1 of every iteration, on every rank with the same q1

@@ -20,6 +20,8 @@
  *                   on P = 4, 16 or 64 ranks, i.e. the bits of `mpirun -np P ./cg n`
  *   CG_SCHEDULE=classic|fused|fused_noq|lean   kernel schedule of the solve path
  *                   (default lean; fused in strict order, which needs q stored)
+ *   CG_STENCIL="up,left,centre,right,down"   other values for the five entries of cg.c:33's
+ *                   coefficient array that the reference's kernels read (default -1,-1,4,-1,-1)
  *   CG_DUMP=prefix  write the final u as raw doubles to <prefix>.u.f64 (1 rank)
  *
  * Output on rank 0: the reference's two lines (cg.c:139-140) followed by one
@@ -92,6 +94,17 @@ int main(int argc, char **argv)
     const int strict = strict_e && *strict_e && *strict_e != '0';
     const int use_calls = path && strcmp(path, "calls") == 0;
 
+    int my_stencil[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};              /* cg.c:33 */
+    const char *ste = getenv("CG_STENCIL");
+    if (ste && *ste) {
+        int v[5];
+        if (sscanf(ste, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5) {
+            if (rank == 0) printf("[ERROR] CG_STENCIL needs five integers: up,left,centre,right,down.\n");
+            return 1;
+        }
+        my_stencil[1] = v[0]; my_stencil[3] = v[1]; my_stencil[4] = v[2]; my_stencil[5] = v[3]; my_stencil[7] = v[4];
+    }
+
     double q1 = 0.0, q_init = 0.0, runtime = 0.0;
     long done_iters = 0;
     int bytes_per_point = 88;
@@ -104,7 +117,6 @@ int main(int argc, char **argv)
         MPI_Settings *settings = init_mpi_settings(numprocs, (int)G);
         device = settings->device;
         settings->strict_dot = strict;
-        int my_stencil[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};          /* cg.c:33 */
         stencil_struct *stencil = (stencil_struct *)malloc(sizeof(stencil_struct));
         stencil->size = 3;
         stencil->extent = stencil->size / 2;
@@ -170,6 +182,7 @@ int main(int argc, char **argv)
         else if (se && strcmp(se, "lean") == 0) sched = CG_SCHED_LEAN;
         CK(cg_set_option(ctx, CG_OPT_REDUCE, strict ? CG_REDUCE_STRICT : CG_REDUCE_FAST), "cg_set_option(reduce)");
         CK(cg_set_option(ctx, CG_OPT_SCHEDULE, sched), "cg_set_option(schedule)");
+        CK(cg_set_stencil(ctx, my_stencil), "cg_set_stencil");
         const char *snp = getenv("CG_STRICT_NP");
         if (strict && snp && *snp) {
             const int p = atoi(snp), side = (int)(sqrt((double)p) + 0.5);

@@ -40,18 +40,12 @@ static int cur_device(void) { return g_settings ? g_settings->device : 0; }
 
 static void check_stencil(const stencil_struct *s)
 {
-    /* Only entries 1,3,4,5,7 are read by the reference (utils.c:27-31); the kernel
-     * hard-codes the same five points with the coefficients -1,-1,4,-1,-1. */
-    static const int want[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};
+    /* The reference's kernels are written for the 3x3 array (utils.c:27-31 index it directly);
+     * its five cross entries are passed on as they are. */
     if (s == NULL || s->size != 3 || s->extent != 1 || s->stencil == NULL) {
         fprintf(stderr, "[ERROR] only the 3x3 stencil of extent 1 is supported\n");
         exit(1);
     }
-    for (int k = 1; k < 9; k += (k == 3 || k == 4) ? 1 : 2)
-        if (s->stencil[k] != want[k]) {
-            fprintf(stderr, "[ERROR] stencil entry %d is %d; the HIP kernel implements {-1,-1,4,-1,-1}\n", k, s->stencil[k]);
-            exit(1);
-        }
 }
 
 /* utils.c:383-420.  chunklength = row length n+1; this rank owns (n+1)/numprocs rows. */
@@ -132,7 +126,7 @@ void apply_stencil_serial(int n, stencil_struct *my_stencil, double *d, double *
 {
     check_stencil(my_stencil);
     const long G = (long)n + 1;
-    CK(cg_stencil(cur_device(), G, 0, G, d, NULL, NULL, q, NULL), "cg_stencil");
+    CK(cg_stencil9(cur_device(), my_stencil->stencil, G, 0, G, d, NULL, NULL, q, NULL), "cg_stencil9");
 }
 
 /* utils.c:221-274, rows only.  Device rows are staged through the host. */
@@ -165,7 +159,7 @@ void apply_stencil_parallel(const int chunklength, stencil_struct *my_stencil, d
 {
     check_stencil(my_stencil);
     exchange_boundaries(chunklength, ld, myrank, s);
-    CK(cg_stencil(s->device, chunklength, s->row0, s->local_rows, ld->locald, ld->top_pad, ld->bottom_pad, localq, NULL),
+    CK(cg_stencil9(s->device, my_stencil->stencil, chunklength, s->row0, s->local_rows, ld->locald, ld->top_pad, ld->bottom_pad, localq, NULL),
        "cg_stencil");
 }
 

@@ -36,7 +36,9 @@ def cg():
 def golden():
     """Records produced by running the reference itself (tests/golden/make_golden.py)."""
     doc = json.load(open(os.path.join(GOLDEN_DIR, "golden.json")))
-    return {(r["n"], r["max_iters"], r["np"], r["rtol"]): r for r in doc["cases"]}
+    # default coefficients: (n, iters, np, rtol); other coefficient sets append the 5-tuple
+    return {(r["n"], r["max_iters"], r["np"], r["rtol"]) + ((tuple(r["stencil"]),) if "stencil" in r else ()): r
+            for r in doc["cases"]}
 
 
 def golden_arrays(stem, n):

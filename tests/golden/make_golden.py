@@ -41,6 +41,14 @@ CASES = [
     (15, 10000, 1, 1e-8, False), (63, 10000, 1, 1e-8, False), (255, 10000, 1, 1e-8, False),
     (1023, 10000, 1, 1e-8, False),
 ]
+# the same with other coefficients in cg.c:33's array: (n, iters, np, (up, left, centre, right, down), dump?)
+STENCIL_CASES = [
+    (15, 10, 1, (-1, -2, 6, -2, -1), True),      # anisotropic, symmetric
+    (63, 50, 1, (-1, -2, 6, -2, -1), False),
+    (63, 50, 4, (-1, -2, 6, -2, -1), False),
+    (255, 100, 1, (-3, -1, 9, -1, -3), False),
+    (63, 20, 1, (-1, -2, 7, -3, -1), False),     # not symmetric: CG is not meant for it, the arithmetic still is defined
+]
 BIG = [
     (4095, 200, 1, 0.0, False),
     (4095, 100000, 4, 1e-8, False),
@@ -51,11 +59,14 @@ LINE = re.compile(r"\[ORACLE\] q1 = (\S+) \((\S+)\) iters=(\d+) np=(\d+) qinit =
                   r"(?: sum_u = (\S+) max_err = (\S+))?")
 
 
-def run_case(n, iters, np_, rtol, dump):
+def run_case(n, iters, np_, rtol, dump, stencil=None):
     env = dict(os.environ, REF_ITERS=str(iters))
     if rtol > 0:
         env["REF_RTOL"] = repr(rtol)
     prefix = os.path.join(HERE, f"n{n}_i{iters}")
+    if stencil is not None:
+        env["REF_STENCIL"] = ",".join(str(x) for x in stencil)
+        prefix += "_s" + "_".join(str(x).replace("-", "m") for x in stencil)
     if dump:
         env["REF_DUMP"] = prefix
     cmd = [REF, str(n)] if np_ == 1 else [MPIRUN, "-np", str(np_), REF, str(n)]
@@ -72,6 +83,8 @@ def run_case(n, iters, np_, rtol, dump):
         rec["max_err"] = m.group(7)
     if dump:
         rec["arrays"] = os.path.basename(prefix)
+    if stencil is not None:
+        rec["stencil"] = list(stencil)
     return rec
 
 
@@ -80,17 +93,22 @@ def main():
         sys.exit("build the reference first:  make -C oracle ref")
     cases = CASES + (BIG if "--big" in sys.argv else [])
     path = os.path.join(HERE, "golden.json")
+    key = lambda r: (r["n"], r["max_iters"], r["np"], r["rtol"], tuple(r.get("stencil", ())))
     old = {}
     if os.path.exists(path):
         for r in json.load(open(path))["cases"]:
-            old[(r["n"], r["max_iters"], r["np"], r["rtol"])] = r
+            old[key(r)] = r
     recs = []
     for c in cases:
         print("running", c, flush=True)
         recs.append(run_case(*c))
-        old.pop((c[0], c[1], c[2], c[3]), None)
+        old.pop(key(recs[-1]), None)
+    for n, iters, np_, stencil, dump in STENCIL_CASES:
+        print("running", (n, iters, np_, stencil), flush=True)
+        recs.append(run_case(n, iters, np_, 0.0, dump, stencil))
+        old.pop(key(recs[-1]), None)
     recs += list(old.values())          # keep long-run records made earlier with --big
-    recs.sort(key=lambda r: (r["n"], r["max_iters"], r["np"], r["rtol"]))
+    recs.sort(key=key)
     doc = {"generator": "tests/golden/make_golden.py (oracle/_ref/cg_ref = reference cg.c+utils.c, "
                         "gcc -std=c99 -O3 -march=x86-64-v3, MPICH 3.3.2)",
            "cases": recs}

@@ -102,3 +102,11 @@ def test_driver_reproduces_the_references_multirank_output(golden, np_):
     lines, m = run(["255"], env={"CG_STRICT": "1", "CG_STRICT_NP": str(np_)})
     assert m.group(2) == rec["q1_hex"]
     assert lines[0] == "[INFO] norm_g^2 = %.16f" % float.fromhex(rec["q1_hex"])
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+@pytest.mark.parametrize("path", ["solve", "calls"])
+def test_driver_with_other_stencil_coefficients(golden, path):
+    rec = golden[(63, 50, 1, 0.0, (-1, -2, 6, -2, -1))]
+    _, m = run(["63", "50"], env={"CG_STRICT": "1", "CG_STENCIL": "-1,-2,6,-2,-1", "CG_PATH": path})
+    assert m.group(2) == rec["q1_hex"]

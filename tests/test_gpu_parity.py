@@ -360,3 +360,52 @@ def test_reference_headline_golden_4096(cg, golden):
     q1_ref = float.fromhex(rec["q1_hex"])
     assert abs(r.q1 - q1_ref) <= FAST_Q1_RTOL * q1_ref
     assert abs(float(np.sum(s.vector(cg.VEC_U))) - float(rec["sum_u"])) <= FAST_U_RTOL * float(rec["sum_u"])
+
+
+# --------------------------------------------- other stencil coefficients -------
+
+STENCIL_KEYS = [(15, 10, 1, (-1, -2, 6, -2, -1)), (63, 50, 1, (-1, -2, 6, -2, -1)), (63, 50, 4, (-1, -2, 6, -2, -1)),
+                (255, 100, 1, (-3, -1, 9, -1, -3)), (63, 20, 1, (-1, -2, 7, -3, -1))]
+
+
+@pytest.mark.parametrize("n,iters,np_,coef", STENCIL_KEYS)
+def test_other_stencil_coefficients_strict_bitwise_against_reference(cg, oracle, golden, n, iters, np_, coef):
+    # The reference takes its five coefficients from the stencil struct (utils.c:27-31); so does the kernel.
+    rec = golden[(n, iters, np_, 0.0, coef)]
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_blocks=int(round(np_ ** 0.5))).set_stencil(coef)
+    r = s.init_problem().solve(iters)
+    assert float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex()
+    if "arrays" in rec:
+        want = golden_arrays(rec["arrays"], n)
+        for k, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+            assert np.array_equal(bits(s.vector(which)), bits(want[k])), k
+    if "sum_u_hex" in rec:
+        assert float(seq_sum(oracle, s.vector(cg.VEC_U))).hex() == rec["sum_u_hex"]
+
+
+@pytest.mark.parametrize("sched", ["classic", "fused", "fused_noq", "lean"])
+def test_other_stencil_coefficients_fast_schedules(cg, oracle, sched):
+    coef = (-1, -2, 6, -2, -1)
+    oracle.set_stencil(coef)
+    try:
+        ref = oracle.cg(255, 60)
+    finally:
+        oracle.set_stencil()
+    s = cg.CGSolver(255).configure(schedule=getattr(cg, SCHEDS[sched])).set_stencil(coef).init_problem()
+    r = s.solve(60)
+    assert abs(r.q1 - ref["q1"]) <= FAST_Q1_RTOL * ref["q1"]
+    assert np.max(np.abs(s.vector(cg.VEC_U) - ref["u"])) <= FAST_U_RTOL * np.max(np.abs(ref["u"]))
+
+
+def test_standalone_stencil_with_coefficients_bitwise(cg, oracle):
+    G, coef = 301, (3, -7, 11, 5, -2)
+    rng = np.random.default_rng(11)
+    d_h = rng.standard_normal((G, G))
+    oracle.set_stencil(coef)
+    try:
+        want = oracle.stencil(d_h)
+    finally:
+        oracle.set_stencil()
+    d, q = cg.DeviceVector.from_host(d_h), cg.DeviceVector(G * G)
+    cg.stencil(G, 0, G, d, q, coef5=coef)
+    assert np.array_equal(bits(q.to_host().reshape(G, G)), bits(want))

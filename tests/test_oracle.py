@@ -122,3 +122,25 @@ def test_oracle_in_the_references_multirank_summation_layout_matches_its_np_outp
     assert res["iters"] == iters
     assert float(res["q1"]).hex() == float.fromhex(rec["q1_hex"]).hex()
     assert float(res["q_init"]).hex() == float.fromhex(rec["q_init_hex"]).hex()
+
+
+STENCIL_KEYS = [(15, 10, 1, (-1, -2, 6, -2, -1)), (63, 50, 1, (-1, -2, 6, -2, -1)), (63, 50, 4, (-1, -2, 6, -2, -1)),
+                (255, 100, 1, (-3, -1, 9, -1, -3)), (63, 20, 1, (-1, -2, 7, -3, -1))]
+
+
+@pytest.mark.parametrize("n,iters,np_,coef", STENCIL_KEYS)
+def test_oracle_with_other_stencil_coefficients_matches_reference(oracle, golden, n, iters, np_, coef):
+    # the reference reads its five coefficients from the struct (utils.c:27-31); goldens made with REF_STENCIL
+    rec = golden[(n, iters, np_, 0.0, coef)]
+    oracle.set_stencil(coef)
+    try:
+        res = oracle.cg(n, iters, blocks2d=None if np_ == 1 else int(round(np_ ** 0.5)))
+    finally:
+        oracle.set_stencil()
+    assert float(res["q1"]).hex() == float.fromhex(rec["q1_hex"]).hex()
+    if "arrays" in rec:
+        want = golden_arrays(rec["arrays"], n)
+        for k in ("u", "g", "d"):
+            assert np.array_equal(bits(res[k]), bits(want[k])), k
+    if "sum_u_hex" in rec:
+        assert float(seq_sum(oracle, res["u"])).hex() == rec["sum_u_hex"]
