@@ -20,7 +20,8 @@
 //      chunk unusable;
 //   C. groups of 64 chunks with one common guess are composed in order
 //      ((D,mn,mx) o (D',mn',mx') = (D+D', min(mn, D+mn'), max(mx, D+mx')));
-//   D. ONE wavefront then walks the groups in order with the true accumulator s:
+//      (and groups of 64 groups once more);
+//   D. ONE wavefront then walks the top level in order with the true accumulator s:
 //      it scans 64 summaries at a time, accepts the longest prefix whose hypothesis
 //      holds for the actual s (right exponent, running value never leaves
 //      [2^52+1, 2^53-1], no flag), and where that fails descends to the chunks of the
@@ -163,6 +164,24 @@ __global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v,
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) approx[c] = acc;
+}
+
+// A': the kernels that produce the operands can hand over approximate sums of every aligned
+// span of kSub consecutive products (one wavefront's worth of a row); eight of them make a
+// chunk sum, and pass A need not read the operands at all.
+constexpr int kSub = 128;
+__global__ __launch_bounds__(256) void k_xs_from_sub(const double *__restrict__ sub, long nsub, long nchunks,
+                                                     double *__restrict__ approx)
+{
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < kChunk / kSub; ++j) {
+        const long i = c * (kChunk / kSub) + j;
+        acc += (i < nsub) ? sub[i] : 0.0;
+    }
+    approx[c] = acc;
 }
 
 // Sum of each group's 64 chunk sums.
@@ -351,34 +370,54 @@ __device__ __forceinline__ double refine(const double *v, const double *w, long 
     return s;
 }
 
+// One group (64 chunk summaries) starting from accumulator s.
+__device__ __forceinline__ double walk_group(const double *v, const double *w, long count, const Summary *chunks,
+                                             long nchunks, long g, double s, int lane)
+{
+    const long cb = g * kGroup;
+    const int nc = (nchunks - cb < 64) ? (int)(nchunks - cb) : 64;
+    const Summary cmine = (lane < nc) ? chunks[cb + lane] : identity();
+    int cpos = 0;
+    while (cpos < nc) {
+        const int cf = walk(cmine, nc, cpos, s, lane);
+        if (cf >= nc) break;
+        const long lo = (cb + cf) * kChunk;
+        const long hi = (lo + kChunk < count) ? lo + kChunk : count;
+        s = refine(v, w, lo, hi, s, lane);
+        cpos = cf + 1;
+    }
+    return s;
+}
+
+// Three levels: 64 super-groups (of 64 groups of 64 chunks) are scanned per step; where a
+// summary does not apply the walk descends one level, down to the elements.
 __global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, const double *__restrict__ w, long count,
                                                 const Summary *__restrict__ chunks, long nchunks,
-                                                const Summary *__restrict__ groups, long ngroups, double start,
+                                                const Summary *__restrict__ groups, long ngroups,
+                                                const Summary *__restrict__ supers, long nsupers, double start,
                                                 const double *start_dev, double *result)
 {
     const int lane = threadIdx.x;
     double s = (start_dev != nullptr) ? *start_dev : start;
-    for (long gb = 0; gb < ngroups; gb += 64) {
-        const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
-        const Summary gmine = (lane < ng) ? groups[gb + lane] : identity();
-        int gpos = 0;
-        while (gpos < ng) {
-            const int gf = walk(gmine, ng, gpos, s, lane);
-            if (gf >= ng) break;
-            // group gb+gf does not apply as a whole: walk its chunks
-            const long cb = (gb + gf) * kGroup;
-            const int nc = (nchunks - cb < 64) ? (int)(nchunks - cb) : 64;
-            const Summary cmine = (lane < nc) ? chunks[cb + lane] : identity();
-            int cpos = 0;
-            while (cpos < nc) {
-                const int cf = walk(cmine, nc, cpos, s, lane);
-                if (cf >= nc) break;
-                const long lo = (cb + cf) * kChunk;
-                const long hi = (lo + kChunk < count) ? lo + kChunk : count;
-                s = refine(v, w, lo, hi, s, lane);
-                cpos = cf + 1;
+    for (long sb = 0; sb < nsupers; sb += 64) {
+        const int ns = (nsupers - sb < 64) ? (int)(nsupers - sb) : 64;
+        const Summary smine = (lane < ns) ? supers[sb + lane] : identity();
+        int spos = 0;
+        while (spos < ns) {
+            const int sf = walk(smine, ns, spos, s, lane);
+            if (sf >= ns) break;
+            // super-group sb+sf does not apply as a whole: walk its groups
+            const long gb = (sb + sf) * kGroup;
+            const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
+            const Summary gmine = (lane < ng) ? groups[gb + lane] : identity();
+            int gpos = 0;
+            while (gpos < ng) {
+                const int gf = walk(gmine, ng, gpos, s, lane);
+                if (gf >= ng) break;
+                s = walk_group(v, w, count, chunks, nchunks, gb + gf, s, lane);
+                gpos = gf + 1;
             }
-            gpos = gf + 1;
+            spos = sf + 1;
         }
     }
     if (lane == 0) *result = s;
@@ -387,7 +426,8 @@ __global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, co
 // Workspace for `count` elements.
 struct Workspace {
     double *approx = nullptr, *goff = nullptr;
-    Summary *chunks = nullptr, *groups = nullptr;
+    double *sub = nullptr;                // span sums handed over by the producing kernel (kSub products each)
+    Summary *chunks = nullptr, *groups = nullptr, *supers = nullptr;
     long cap_chunks = 0;
 
     static long chunks_for(long count) { return (count + kChunk - 1) / kChunk; }
@@ -396,8 +436,10 @@ struct Workspace {
         const long nc = chunks_for(count);
         if (nc <= cap_chunks) return hipSuccess;
         release();
-        const long ng = (nc + kGroup - 1) / kGroup;
+        const long ng = (nc + kGroup - 1) / kGroup, nsup = (ng + kGroup - 1) / kGroup;
         hipError_t e;
+        if ((e = hipMalloc(&sub, (size_t)nc * (kChunk / kSub) * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&supers, (size_t)nsup * sizeof(Summary))) != hipSuccess) return e;
         if ((e = hipMalloc(&approx, (size_t)nc * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&goff, (size_t)ng * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&chunks, (size_t)nc * sizeof(Summary))) != hipSuccess) return e;
@@ -408,33 +450,43 @@ struct Workspace {
     void release()
     {
         (void)hipFree(approx); (void)hipFree(goff); (void)hipFree(chunks); (void)hipFree(groups);
-        approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; cap_chunks = 0;
+        (void)hipFree(sub); (void)hipFree(supers);
+        approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; sub = nullptr; supers = nullptr;
+        cap_chunks = 0;
     }
 };
 
 // result <- the reference's sequential dot product of v and w started from `start`, or from
 // *start_dev (read on the device when the kernels run: a value an earlier kernel or a
 // neighbouring rank produced) when start_dev is not null.  `result` may alias `start_dev`.
-// Stream-ordered; the workspace must have been reserved for `count`.
+// Stream-ordered; the workspace must have been reserved for `count`.  have_sub: ws.sub already
+// holds approximate sums of every aligned span of kSub products (written by the kernel that
+// produced v and w), so the operands are read once instead of twice.  Those sums only steer
+// the guesses; every guess is verified by the walk, so their accuracy affects speed, never bits.
 inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
-                    double *result, const double *start_dev = nullptr)
+                    double *result, const double *start_dev = nullptr, bool have_sub = false)
 {
     if (count <= 0) {
-        hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, 0L, ws.chunks, 0L, ws.groups, 0L, start,
-                           start_dev, result);
+        hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, 0L, ws.chunks, 0L, ws.groups, 0L, ws.supers, 0L,
+                           start, start_dev, result);
         return;
     }
     const long nc = Workspace::chunks_for(count);
-    const long ng = (nc + kGroup - 1) / kGroup;
-    const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4);
+    const long ng = (nc + kGroup - 1) / kGroup, nsup = (ng + kGroup - 1) / kGroup;
+    const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4), sb = (unsigned)((nsup + 3) / 4);
     const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;
-    hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
+    if (have_sub)
+        hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub,
+                           (count + kSub - 1) / kSub, nc, ws.approx);
+    else
+        hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
     hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
     hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, start_dev);
     hipLaunchKernelGGL(k_xs_chunk, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
-    hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, start,
-                       start_dev, result);
+    hipLaunchKernelGGL(k_xs_group, dim3(sb), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup);
+    hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, ws.supers, nsup,
+                       start, start_dev, result);
 }
 
 } // namespace exact

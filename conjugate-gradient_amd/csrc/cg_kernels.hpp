@@ -139,6 +139,9 @@ struct StencilArgs {
     int edge_pair;                    // 1 = this launch covers row tiles 0 and rt_total-1 only
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
     Coef5 coef;                       // stencil coefficients
+    double *sub;                      // MODE 0/1 with VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
+                                      // every aligned 128-element span (one wavefront's part of a row), at
+                                      // sub[(r*G + column)/128] -- approximate chunk sums for the strict-order dot
 };
 
 // Streaming accesses carry the non-temporal hint (global_load/store ... nt): every
@@ -438,8 +441,16 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     BufIO<VEC>::store(row_rsrc_nn(a.u + m * G, row_own ? rowbytes : 0), off_main, pu);
                 }
             } else {
+                double span = 0.0;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc += mid[v] * qv[v];   // q = 0 off the interior
+                for (int v = 0; v < VEC; ++v) {
+                    acc += mid[v] * qv[v];                             // q = 0 off the interior
+                    span += mid[v] * qv[v];
+                }
+                if ((MODE == 0 || MODE == 1) && VEC == 2 && a.sub != nullptr) {    // wave-uniform
+                    span = wave_sum(span);
+                    if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
+                }
                 if (WRITE_Q) {
                     const __amdgpu_buffer_rsrc_t rq = row_rsrc_nn(a.q + m * G, row_in ? rowbytes : 0);
                     BufIO<VEC>::store(rq, off_qv, qv);
@@ -469,24 +480,37 @@ template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_update(double *__restrict__ u, double *__restrict__ g,
                                                    const double *__restrict__ d,
                                                    const double *__restrict__ q, long count,
-                                                   const Scalars *sc, double *partials)
+                                                   const Scalars *sc, double *partials, double *sub)
 {
     if (sc->done) return;
     __shared__ double wave_slots[kWaves];
     const double tau = sc->tau;
     const long nvec = count / VEC;
     const long stride = (long)gridDim.x * kBlock;
+    const long rounds = (nvec + stride - 1) / stride;       // every lane makes the same number of trips (wave_sum below)
     double acc = 0.0;
-    for (long k = (long)blockIdx.x * kBlock + threadIdx.x; k < nvec; k += stride) {
-        Pack<VEC> pu, pg, pd, pq;
-        pu.load(u + k * VEC); pg.load(g + k * VEC); pd.load(d + k * VEC); pq.load(q + k * VEC);
+    for (long it = 0; it < rounds; ++it) {
+        const long k = it * stride + (long)blockIdx.x * kBlock + threadIdx.x;
+        double span = 0.0;
+        if (k < nvec) {
+            Pack<VEC> pu, pg, pd, pq;
+            pu.load(u + k * VEC); pg.load(g + k * VEC); pd.load(d + k * VEC); pq.load(q + k * VEC);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            pu.v[v] = pu.v[v] + tau * pd.v[v];
-            pg.v[v] = pg.v[v] + tau * pq.v[v];
-            acc += pg.v[v] * pg.v[v];
+            for (int v = 0; v < VEC; ++v) {
+                pu.v[v] = pu.v[v] + tau * pd.v[v];
+                pg.v[v] = pg.v[v] + tau * pq.v[v];
+                acc += pg.v[v] * pg.v[v];
+                span += pg.v[v] * pg.v[v];
+            }
+            pu.store(u + k * VEC); pg.store(g + k * VEC);
         }
-        pu.store(u + k * VEC); pg.store(g + k * VEC);
+        // VEC 2: a wavefront's 64 lanes hold 128 consecutive elements starting at a multiple of 128:
+        // their g.g goes to sub[] as approximate input for the strict-order dot product
+        if (VEC == 2 && sub != nullptr) {
+            span = wave_sum(span);
+            const long first = (k - (threadIdx.x & 63)) * 2;
+            if ((threadIdx.x & 63) == 0 && first < count) sub[first >> 7] = span;
+        }
     }
     const double s = block_sum(acc, wave_slots);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;

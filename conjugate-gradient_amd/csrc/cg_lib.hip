@@ -321,8 +321,19 @@ void drop_graph(cg_ctx *c)
 // the fused schedules have no pending d update.  Every launch is
 // stream-ordered; nothing here synchronises, so the same code runs eagerly and
 // under stream capture.
+// Strict order, parallel evaluation: may the kernel that produces the operands hand over
+// approximate span sums (cg::exact::kSub products each)?  Needs 16-byte rows whose length is a
+// multiple of the span, so that spans never straddle rows; not used with the 2-D block layout.
+double *strict_sub(const cg_ctx *c, const TileGeom &t)
+{
+    if (c->reduce != CG_REDUCE_STRICT || c->strict_blocks > 1) return nullptr;
+    if (!use_parallel_strict(c->strict_impl, c->count)) return nullptr;
+    if (t.vec != 2 || c->G % cg::exact::kSub != 0) return nullptr;
+    return c->xs.sub;
+}
+
 int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *partials, long npart,
-                       int what, double rtol)
+                       int what, double rtol, bool have_sub = false)
 {
     // Completes a dot product whose fast-order block partials are already in
     // `partials` (npart of them), or, in strict mode, recomputes it with the
@@ -362,7 +373,7 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
             double *slot = c->nranks > 1 ? c->comm->gather_buf() + c->rank : c->strict_slot;
             const double *seed = k > 0 ? c->comm->gather_buf() + (k - 1) : nullptr;
             if (k == c->rank) {
-                if (par) cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, slot, seed);   // workspace reserved by cg_solve
+                if (par) cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, slot, seed, have_sub);   // workspace reserved by cg_solve
                 else hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, seed, slot);
             }
             if (c->nranks > 1) CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
@@ -474,6 +485,8 @@ int enqueue_iteration(cg_ctx *c, bool first)
     StencilArgs a = base_args(c, t);
     a.partials = p_dq;
     a.q = c->q;
+    double *const sub = strict_sub(c, t);                  // both dot products use it, one after the other
+    a.sub = (sched == CG_SCHED_FUSED_NOQ) ? nullptr : sub;    // (that schedule stores no q: never strict)
     const bool fuse = (sched != CG_SCHED_CLASSIC) && !first;
     bool split = false;                   // interior tiles run beside the halo exchange
     if (c->nranks > 1) {
@@ -532,10 +545,11 @@ int enqueue_iteration(cg_ctx *c, bool first)
         }
     }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0));
+    CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0, a.sub != nullptr));
 
     // ---- u += tau d ; g += tau q (+ g.g)
     long npart_gg;
+    double *gg_sub = nullptr;
     if (sched == CG_SCHED_FUSED_NOQ) {
         StencilArgs b = base_args(c, t);
         b.d_in = c->d[c->dcur];
@@ -545,14 +559,15 @@ int enqueue_iteration(cg_ctx *c, bool first)
         launch_stencil<2, false>(t, b, s);
         npart_gg = t.ntiles;
     } else {
+        gg_sub = sub;
         if (t.vec == 2)
-            hipLaunchKernelGGL(cg::k_update<2>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg);
+            hipLaunchKernelGGL(cg::k_update<2>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg, gg_sub);
         else
-            hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg);
+            hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg, gg_sub);
         npart_gg = fb;
     }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0));
+    CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0, gg_sub != nullptr));
 
     // ---- d = beta d - g: now (classic) or inside the next stencil kernel (fused)
     if (sched == CG_SCHED_CLASSIC) {
@@ -1230,9 +1245,9 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
                 b.d_in = c->d[c->dcur]; b.u = c->u; b.gw = c->g; b.partials = c->partials + c->npart;
                 launch_stencil<2, false>(t, b, s);
             } else if (t.vec == 2) {
-                hipLaunchKernelGGL(cg::k_update<2>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, c->partials + c->npart);
+                hipLaunchKernelGGL(cg::k_update<2>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, c->partials + c->npart, (double *)nullptr);
             } else {
-                hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, c->partials + c->npart);
+                hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, c->partials + c->npart, (double *)nullptr);
             }
         } else {
             if (t.vec == 2) hipLaunchKernelGGL(cg::k_dupdate<2>, dim3(fb), dim3(kBlock), 0, s, c->d[c->dcur], c->g, c->count, c->sc, 0);
