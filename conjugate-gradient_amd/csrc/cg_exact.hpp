@@ -130,11 +130,26 @@ __device__ __forceinline__ Summary piece_summary(const double (&p)[kPerLane], in
     return s;
 }
 
+// Product k of the sequence that is summed; w == nullptr means v already holds the rounded
+// products (the producing kernel formed fl(v*w) with the same single rounding).
+__device__ __forceinline__ double product(const double *v, const double *w, long k)
+{
+    return (w != nullptr) ? v[k] * w[k] : v[k];
+}
+
 // Two consecutive products starting at even index i (zero beyond `count`).
 __device__ __forceinline__ void product_pair(const double *__restrict__ v, const double *__restrict__ w, long i,
                                              long count, bool vec, double &p0, double &p1)
 {
-    if (vec && i + 1 < count) {
+    if (w == nullptr) {
+        if (vec && i + 1 < count) {
+            const xv2 a = __builtin_nontemporal_load(reinterpret_cast<const xv2 *>(v + i));
+            p0 = a.x; p1 = a.y;
+        } else {
+            p0 = (i < count) ? v[i] : 0.0;
+            p1 = (i + 1 < count) ? v[i + 1] : 0.0;
+        }
+    } else if (vec && i + 1 < count) {
         const xv2 a = __builtin_nontemporal_load(reinterpret_cast<const xv2 *>(v + i));
         const xv2 b = __builtin_nontemporal_load(reinterpret_cast<const xv2 *>(w + i));
         p0 = a.x * b.x; p1 = a.y * b.y;
@@ -300,7 +315,7 @@ __device__ __forceinline__ double replay(const double *v, const double *w, long 
 {
     for (long base = lo; base < hi; base += 64) {
         const long i = base + lane;
-        const double p = (i < hi) ? v[i] * w[i] : 0.0;
+        const double p = (i < hi) ? product(v, w, i) : 0.0;
         const int m = (hi - base < 64) ? (int)(hi - base) : 64;
         if (m == 64) {
 #pragma unroll
@@ -350,7 +365,7 @@ __device__ __forceinline__ double refine(const double *v, const double *w, long 
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         const long idx = lo + (long)lane * kPerLane + i;
-        p[i] = (idx < hi) ? v[idx] * w[idx] : 0.0;
+        p[i] = (idx < hi) ? product(v, w, idx) : 0.0;
     }
     int piece = 0;
     for (int round = 0; piece < 64; ++round) {
@@ -474,7 +489,7 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup, nsup = (ng + kGroup - 1) / kGroup;
     const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4), sb = (unsigned)((nsup + 3) / 4);
-    const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;
+    const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;   // (null w: v alone)
     if (have_sub)
         hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub,
                            (count + kSub - 1) / kSub, nc, ws.approx);

@@ -139,8 +139,9 @@ struct StencilArgs {
     int edge_pair;                    // 1 = this launch covers row tiles 0 and rt_total-1 only
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
     Coef5 coef;                       // stencil coefficients
-    double *sub;                      // MODE 0/1 with VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
-                                      // every aligned 128-element span (one wavefront's part of a row), at
+    int store_products;               // WRITE_Q kernels: store d*q (rounded) where q would go
+    double *sub;                      // MODE 0/1/2 with VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
+                                      // (MODE 2: g.g) of every aligned 128-element span (one wavefront's part of a row), at
                                       // sub[(r*G + column)/128] -- approximate chunk sums for the strict-order dot
 };
 
@@ -423,6 +424,12 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 }
                 BufIO<VEC>::store(row_rsrc_nn(a.u +m * G, row_own ? rowbytes : 0), off_main, pu);
                 BufIO<VEC>::store(row_rsrc_nn(a.gw +m * G, row_own ? rowbytes : 0), off_main, pg);
+                if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
+                    double span = pg[0] * pg[0];
+                    span += pg[VEC - 1] * pg[VEC - 1];
+                    span = wave_sum(span);
+                    if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
+                }
             } else if (MODE == 4 || MODE == 5) {
                 double pg[VEC];
 #pragma unroll
@@ -452,11 +459,16 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
                 }
                 if (WRITE_Q) {
+                    // q itself, or (strict order without a stored q) the rounded products d*q that the
+                    // sequential sum adds up -- the one thing the strict evaluation needs from q
+                    double out[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) out[v] = a.store_products ? mid[v] * qv[v] : qv[v];
                     const __amdgpu_buffer_rsrc_t rq = row_rsrc_nn(a.q + m * G, row_in ? rowbytes : 0);
-                    BufIO<VEC>::store(rq, off_qv, qv);
+                    BufIO<VEC>::store(rq, off_qv, out);
                     if (VEC == 2) {
-                        buf_store1(rq, off_q0, qv[0]);
-                        buf_store1(rq, off_q1, qv[VEC - 1]);
+                        buf_store1(rq, off_q0, out[0]);
+                        buf_store1(rq, off_q1, out[VEC - 1]);
                     }
                 }
             }
@@ -640,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_dot_partial(const double *__restrict
 }
 
 // v.w with a single accumulator in strict index order -- the reference's exact
-// summation (utils.c:372-379).  One wavefront: the lanes fetch 64 consecutive
+// summation (utils.c:372-379).  w == nullptr: v already holds the rounded products.  One wavefront: the lanes fetch 64 consecutive
 // products at a time (coalesced), then every lane replays the same 64 dependent
 // additions, reading product l from lane l.  The result is bit-identical to the
 // CPU loop; the price is one dependent fp64 add per element.
@@ -652,13 +664,13 @@ __global__ __launch_bounds__(64) void k_dot_strict(const double *__restrict__ v,
     double acc = (start_dev != nullptr) ? *start_dev : start;     // device-resident seed: chained ranks
     long base = 0;
     for (; base + 64 <= count; base += 64) {
-        const double p = v[base + lane] * w[base + lane];
+        const double p = (w != nullptr) ? v[base + lane] * w[base + lane] : v[base + lane];
 #pragma unroll
         for (int l = 0; l < 64; ++l) acc += __shfl(p, l, 64);
     }
     const long rem = count - base;
     if (rem > 0) {
-        const double p = (lane < rem) ? v[base + lane] * w[base + lane] : 0.0;
+        const double p = (lane < rem) ? ((w != nullptr) ? v[base + lane] * w[base + lane] : v[base + lane]) : 0.0;
         for (int l = 0; l < rem; ++l) acc += __shfl(p, l, 64);
     }
     if (lane == 0) *result = acc;

@@ -274,7 +274,7 @@ struct cg_ctx {
     int effective_schedule() const
     {
         if (schedule >= 0) return schedule;
-        if (reduce == CG_REDUCE_STRICT) return CG_SCHED_FUSED;                     // strict order needs q stored
+        if (reduce == CG_REDUCE_STRICT) return CG_SCHED_FUSED_NOQ;                 // (stores the products d*q where q would go)
         return lean_unavailable ? CG_SCHED_FUSED_NOQ : CG_SCHED_LEAN;
     }
     void set_gcur(int k)
@@ -337,7 +337,8 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
 {
     // Completes a dot product whose fast-order block partials are already in
     // `partials` (npart of them), or, in strict mode, recomputes it with the
-    // sequential kernel from v and w; then runs the scalar recurrence `what`.
+    // sequential kernel from v and w (w == nullptr: v already holds the products); then runs
+    // the scalar recurrence `what`.
     hipStream_t s = c->stream;
     const double *src = nullptr;
     int nsrc = 1;
@@ -357,8 +358,9 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
             for (long r = 0; r < sdim * sdim; ++r) {
                 const long ci = r / sdim, cj = r % sdim;
                 hipLaunchKernelGGL(cg::k_pack_block, dim3(pb), dim3(kBlock), 0, s, v, c->G, ci * cl, cj * cl, cl, c->pack[0]);
-                if (w != v) hipLaunchKernelGGL(cg::k_pack_block, dim3(pb), dim3(kBlock), 0, s, w, c->G, ci * cl, cj * cl, cl, c->pack[1]);
-                const double *pv = c->pack[0], *pw = (w != v) ? c->pack[1] : c->pack[0];
+                if (w != v && w != nullptr)
+                    hipLaunchKernelGGL(cg::k_pack_block, dim3(pb), dim3(kBlock), 0, s, w, c->G, ci * cl, cj * cl, cl, c->pack[1]);
+                const double *pv = c->pack[0], *pw = (w == nullptr) ? nullptr : ((w != v) ? c->pack[1] : c->pack[0]);   // null: v holds products
                 if (par) cg::exact::enqueue(s, c->xs, pv, pw, n2, 0.0, c->block_sums + r);
                 else hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, pv, pw, n2, 0.0, nullptr, c->block_sums + r);
             }
@@ -486,7 +488,11 @@ int enqueue_iteration(cg_ctx *c, bool first)
     a.partials = p_dq;
     a.q = c->q;
     double *const sub = strict_sub(c, t);                  // both dot products use it, one after the other
-    a.sub = (sched == CG_SCHED_FUSED_NOQ) ? nullptr : sub;    // (that schedule stores no q: never strict)
+    a.sub = sub;
+    // FUSED_NOQ keeps no q.  The strict order needs the products d*q in index order, not q itself: there
+    // the stencil kernel stores them (rounded once, as the reference's loop rounds them) where q would go.
+    const bool products = (sched == CG_SCHED_FUSED_NOQ) && c->reduce == CG_REDUCE_STRICT;
+    a.store_products = products ? 1 : 0;
     const bool fuse = (sched != CG_SCHED_CLASSIC) && !first;
     bool split = false;                   // interior tiles run beside the halo exchange
     if (c->nranks > 1) {
@@ -523,14 +529,14 @@ int enqueue_iteration(cg_ctx *c, bool first)
         a.g_bot = c->has_bot() ? c->halo_g[1] : nullptr;
         a.d_top_out = c->has_top() ? c->halo_d[out][0] : nullptr;
         a.d_bot_out = c->has_bot() ? c->halo_d[out][1] : nullptr;
-        if (sched == CG_SCHED_FUSED) launch_stencil<1, true>(t, a, s);
+        if (sched == CG_SCHED_FUSED || products) launch_stencil<1, true>(t, a, s);
         else launch_stencil<1, false>(t, a, s);
         c->dcur = out;
     } else {
         a.d_in = c->d[c->dcur];
         a.d_top = c->has_top() ? c->halo_d[c->dcur][0] : nullptr;
         a.d_bot = c->has_bot() ? c->halo_d[c->dcur][1] : nullptr;
-        if (sched == CG_SCHED_FUSED_NOQ) {
+        if (sched == CG_SCHED_FUSED_NOQ && !products) {
             launch_stencil<0, false>(t, a, s);
         } else if (!split) {
             launch_stencil<0, true>(t, a, s);
@@ -545,7 +551,8 @@ int enqueue_iteration(cg_ctx *c, bool first)
         }
     }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0, a.sub != nullptr));
+    if (products) CGCHK(enqueue_dot_finish(c, c->q, nullptr, p_dq, t.ntiles, 0, 0.0, a.sub != nullptr));
+    else CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0, a.sub != nullptr));
 
     // ---- u += tau d ; g += tau q (+ g.g)
     long npart_gg;
@@ -556,6 +563,7 @@ int enqueue_iteration(cg_ctx *c, bool first)
         b.d_top = c->has_top() ? c->halo_d[c->dcur][0] : nullptr;
         b.d_bot = c->has_bot() ? c->halo_d[c->dcur][1] : nullptr;
         b.u = c->u; b.gw = c->g; b.partials = p_gg;
+        b.sub = gg_sub = sub;
         launch_stencil<2, false>(t, b, s);
         npart_gg = t.ntiles;
     } else {
@@ -1034,8 +1042,8 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     if (!c || !out) return fail(CG_ERR_ARG, "cg_solve: NULL argument");
     if (max_iters < 0 || rtol < 0) return fail(CG_ERR_ARG, "cg_solve: max_iters and rtol must be >= 0");
     CGCHK(select_device(c->device));
-    if (c->reduce == CG_REDUCE_STRICT && (c->effective_schedule() == CG_SCHED_FUSED_NOQ || c->effective_schedule() == CG_SCHED_LEAN))
-        return fail(CG_ERR_STATE, "strict reduction order needs a schedule that stores q (CLASSIC or FUSED)");
+    if (c->reduce == CG_REDUCE_STRICT && c->effective_schedule() == CG_SCHED_LEAN)
+        return fail(CG_ERR_STATE, "the strict reduction order needs d and the products d*q in memory: CLASSIC, FUSED or FUSED_NOQ");
     if (c->nranks > 1 && !c->comm) return fail(CG_ERR_STATE, "multi-rank context without cg_comm_init");
     if (c->effective_schedule() == CG_SCHED_LEAN) CGCHK(lean_setup(c));   // may fall back to FUSED_NOQ (auto schedule only)
     const int sched = c->effective_schedule();
@@ -1178,7 +1186,7 @@ int cg_copy_out(cg_ctx *c, int which, double *host_dst, long count)
     if (count != c->count) return fail(CG_ERR_ARG, "cg_copy_out: count %ld != block size %ld", count, c->count);
     CGCHK(select_device(c->device));
     if (which == CG_VEC_Q && !c->q_valid)
-        return fail(CG_ERR_STATE, "q is not stored by the FUSED_NOQ schedule; use CLASSIC or FUSED to read it");
+        return fail(CG_ERR_STATE, "q is not stored by the LEAN and FUSED_NOQ schedules; use CLASSIC or FUSED to read it");
     double *src;
     CGCHK(cg_device_ptr(c, which, &src));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -138,8 +138,8 @@ class CGSolver:
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
-            if schedule is None and reduce == _l.REDUCE_STRICT and self.schedule in (_l.SCHED_FUSED_NOQ, _l.SCHED_LEAN):
-                schedule = -1                     # those do not store q: let the library pick (FUSED)
+            if schedule is None and reduce == _l.REDUCE_STRICT and self.schedule == _l.SCHED_LEAN:
+                schedule = -1                     # LEAN keeps neither d' nor q in memory: let the library pick
         if schedule is not None:
             self.set_option(_l.OPT_SCHEDULE, schedule)
             self.schedule = schedule if schedule >= 0 else None
