@@ -409,3 +409,33 @@ def test_standalone_stencil_with_coefficients_bitwise(cg, oracle):
     d, q = cg.DeviceVector.from_host(d_h), cg.DeviceVector(G * G)
     cg.stencil(G, 0, G, d, q, coef5=coef)
     assert np.array_equal(bits(q.to_host().reshape(G, G)), bits(want))
+
+
+# ------------------------------------------------------------ smallest grids -----
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("mode", ["strict", "lean", "fused_noq", "classic"])
+def test_smallest_grids_bitwise_or_close(cg, oracle, n, mode):
+    # a 3x3 grid has ONE interior point; rows shorter than a wavefront, fewer rows than the prefetch depth
+    iters = 3
+    ref = oracle.cg(n, iters)
+    s = cg.CGSolver(n)
+    if mode == "strict":
+        s.configure(reduce=cg.REDUCE_STRICT)
+    else:
+        s.configure(schedule=getattr(cg, SCHEDS[mode]))
+    r = s.init_problem().solve(iters)
+    assert r.iters == iters
+    if mode == "strict":
+        assert np.array_equal(bits(s.history(iters)), bits(ref["hist"]))
+        for k, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+            assert np.array_equal(bits(s.vector(which)), bits(ref[k])), k
+    else:
+        # tiny sums: the fast order can differ in the last bits only.  These few-point grids converge within
+        # the three iterations; a residual that is pure rounding noise (1e-30 and below) is not compared.
+        h, hr = s.history(iters), ref["hist"]
+        live = hr > 1e-25
+        assert np.allclose(h[live], hr[live], rtol=1e-11, atol=0)
+        assert np.array_equal(np.isnan(h), np.isnan(hr))              # 0/0 after an exactly zero residual, as in the reference
+        assert np.all((h[~live] < 1e-25) | np.isnan(h[~live]))
+        assert np.allclose(s.vector(cg.VEC_U), ref["u"], rtol=1e-11, atol=1e-15, equal_nan=True)
