@@ -29,6 +29,18 @@ def test_multirank_matches_single_rank(oracle, tmp_path, schedule, world, n, ite
     assert np.allclose(res[0]["hist"], ref["hist"], rtol=5e-8, atol=0)
 
 
+@pytest.mark.parametrize("schedule", ["classic", "lean"])
+@pytest.mark.parametrize("world,n,iters", [(4, 7, 6), (8, 7, 6), (8, 15, 10)])
+def test_multirank_blocks_of_one_or_two_rows(oracle, tmp_path, schedule, world, n, iters):
+    # every row of a block is an edge row: halo rows on both sides, no interior tiles to overlap with
+    res = run_ranks(world, ["gpu", n, iters, tmp_path, schedule], tmp_path)
+    ref = oracle.cg(n, iters)
+    assert all(float(r["q1"]).hex() == float(res[0]["q1"]).hex() for r in res)
+    live = ref["hist"] > 1e-25
+    assert np.allclose(np.asarray(res[0]["hist"])[live], ref["hist"][live], rtol=1e-10, atol=0)
+    assert np.max(np.abs(stack(res, "u") - ref["u"])) <= 1e-10 * np.max(np.abs(ref["u"]))
+
+
 def test_multirank_stop_rule(oracle, tmp_path):
     n = 63
     res = run_ranks(4, ["gpu", n, 10000, tmp_path, "lean", 1e-8], tmp_path)
