@@ -199,18 +199,24 @@ __global__ __launch_bounds__(256) void k_xs_from_sub(const double *__restrict__ 
     approx[c] = acc;
 }
 
-// Sum of each group's 64 chunk sums.
-__global__ __launch_bounds__(256) void k_xs_gsum(const double *__restrict__ approx, long nchunks,
+// Sum of each group's 64 chunk sums; the chunk sums themselves are replaced by their exclusive
+// prefix inside the group (what precedes the chunk in its group).
+__global__ __launch_bounds__(256) void k_xs_gsum(double *__restrict__ approx, long nchunks,
                                                  double *__restrict__ gsum, long ngroups)
 {
     const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= ngroups) return;
     const long i = g * kGroup + lane;
-    double acc = (i < nchunks) ? approx[i] : 0.0;
+    const double mine = (i < nchunks) ? approx[i] : 0.0;
+    double inc = mine;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) gsum[g] = acc;
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += up;
+    }
+    if (i < nchunks) approx[i] = inc - mine;
+    if (lane == 63) gsum[g] = inc;
 }
 
 // In-place exclusive scan of the group sums, seeded with `start` (or, when `start_dev` is
@@ -244,6 +250,8 @@ __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, lo
 }
 
 // ---- B: per-chunk integer summaries under the guessed exponent --------------------
+// Persistent wavefronts: each walks its own run of chunks and keeps the NEXT chunk's products in
+// flight while it summarises the current one.
 __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, const double *__restrict__ w,
                                                   long count, long nchunks, int vec, const double *__restrict__ approx,
                                                   const double *__restrict__ goff, Summary *__restrict__ out)
@@ -253,35 +261,49 @@ __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, 
     // 16 lanes of a group on distinct banks.
     __shared__ __attribute__((aligned(16))) double tile[4][64 * 18];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long c = (long)blockIdx.x * 4 + wv;
-    if (c >= nchunks) return;                       // whole wavefront leaves together
-    const long base = c * kChunk;
+    // Each wavefront owns a run of consecutive chunks: the chip's reads are then spread over as
+    // many distant regions as there are wavefronts, which this memory system serves faster than one
+    // dense moving window (same effect as in the tiled solver kernels).
+    const long nwaves = (long)gridDim.x * 4, wid = (long)blockIdx.x * 4 + wv;
+    const long per = (nchunks + nwaves - 1) / nwaves;
+    long c = wid * per;
+    const long cend = (c + per < nchunks) ? c + per : nchunks;
     double *T = tile[wv];
+    if (c >= cend) return;                          // whole wavefront leaves together
+
+    double nxt[kPerLane];
+    auto fetch = [&](long chunk) {
 #pragma unroll
-    for (int k = 0; k < kPerLane / 2; ++k) {
-        const int pos = k * 128 + 2 * lane;
-        double p0, p1;
-        product_pair(v, w, base + pos, count, vec != 0, p0, p1);
-        double *dst = T + (pos >> 4) * 18 + (pos & 15);
-        dst[0] = p0; dst[1] = p1;
+        for (int k = 0; k < kPerLane / 2; ++k)
+            product_pair(v, w, chunk * kChunk + k * 128 + 2 * lane, count, vec != 0, nxt[2 * k], nxt[2 * k + 1]);
+    };
+    fetch(c);
+    for (; c < cend; ++c) {
+        double cur[kPerLane];
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) cur[i] = nxt[i];
+        // guess of the accumulator at the chunk's start: scanned group offset + what precedes the chunk in its group
+        const int e = exponent_of(goff[c >> 6] + approx[c]);
+        if (c + 1 < cend) fetch(c + 1);                       // in flight during the work below
+
+#pragma unroll
+        for (int k = 0; k < kPerLane / 2; ++k) {
+            const int pos = k * 128 + 2 * lane;
+            double *dst = T + (pos >> 4) * 18 + (pos & 15);
+            dst[0] = cur[2 * k]; dst[1] = cur[2 * k + 1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double p[kPerLane];
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) p[i] = T[lane * 18 + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the next round's writes
+        __builtin_amdgcn_wave_barrier();
+
+        const Summary s = wave_compose(piece_summary(p, e));
+        if (lane == 0) out[c] = s;
     }
-    // Guess of the accumulator at the chunk's start: scanned group offset + the chunk sums
-    // that precede this chunk inside its group.
-    const long gfirst = c & ~(long)(kGroup - 1);
-    double before = (gfirst + lane < c) ? approx[gfirst + lane] : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-    const int e = exponent_of(goff[c >> 6] + before);
-
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double p[kPerLane];
-#pragma unroll
-    for (int i = 0; i < kPerLane; ++i) p[i] = T[lane * 18 + i];
-
-    const Summary s = wave_compose(piece_summary(p, e));
-    if (lane == 0) out[c] = s;
 }
 
 // ---- C: groups of 64 chunk summaries -------------------------------------------------
@@ -497,7 +519,8 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
         hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
     hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
     hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, start_dev);
-    hipLaunchKernelGGL(k_xs_chunk, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
+    const unsigned cbp = cb < 1024u ? cb : 1024u;          // persistent: the four workgroups per CU that LDS allows
+    hipLaunchKernelGGL(k_xs_chunk, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
     hipLaunchKernelGGL(k_xs_group, dim3(sb), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup);
     hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, ws.supers, nsup,
