@@ -32,12 +32,20 @@ public:
     virtual ~Comm()
     {
         if (gather_) (void)hipFree(gather_);
+        if (block_) (void)hipFree(block_);
     }
     const char *error() const { return err_; }
     // Device buffer of nranks doubles; slot `rank` is this rank's contribution.
     double *gather_buf() { return gather_; }
     // In-place all-gather of one double per rank, ordered after prior work on s.
-    virtual int allgather_scalar(hipStream_t s) = 0;
+    int allgather_scalar(hipStream_t s) { return allgather(s, gather_, 1); }
+    // Device buffer of nranks * kBlockCap doubles for all-gathers of `count` doubles per rank
+    // (count <= kBlockCap): rank r's contribution sits at block_buf() + r*count.
+    static constexpr long kBlockCap = 8192;
+    double *block_buf() { return block_; }
+    int allgather_block(hipStream_t s, long count) { return allgather(s, block_, count); }
+    // In-place all-gather inside `buf`: `count` doubles per rank, rank r's at buf + r*count.
+    virtual int allgather(hipStream_t s, double *buf, long count) = 0;
     // Send the block's first row up and its last row down; receive the neighbours'
     // boundary rows into top_dst / bot_dst.  Ordered after prior work on s.
     virtual int exchange_rows(hipStream_t s, const double *base, long rows, long G, double *top_dst, double *bot_dst) = 0;
@@ -54,11 +62,13 @@ public:
 protected:
     bool alloc_gather(int nranks)
     {
+        const size_t blk = (size_t)nranks * kBlockCap * sizeof(double);
         return hipMalloc(&gather_, (size_t)nranks * sizeof(double)) == hipSuccess &&
                hipMemset(gather_, 0, (size_t)nranks * sizeof(double)) == hipSuccess &&
+               hipMalloc(&block_, blk) == hipSuccess && hipMemset(block_, 0, blk) == hipSuccess &&
                hipStreamSynchronize(nullptr) == hipSuccess;
     }
-    double *gather_ = nullptr;
+    double *gather_ = nullptr, *block_ = nullptr;
     int rank_ = 0, nranks_ = 1;
     bool has_top_ = false, has_bot_ = false;
     char err_[256] = "";
@@ -161,9 +171,9 @@ public:
 
     bool stream_ordered() const override { return true; }
 
-    int allgather_scalar(hipStream_t s) override
+    int allgather(hipStream_t s, double *buf, long count) override
     {
-        return check(api_->AllGather(gather_ + rank_, gather_, 1, ncclDouble, comm_, s), "ncclAllGather");
+        return check(api_->AllGather(buf + (long)rank_ * count, buf, (size_t)count, ncclDouble, comm_, s), "ncclAllGather");
     }
 
     // One grouped RCCL launch for the (up to) two sends and two receives.
@@ -216,7 +226,7 @@ public:
         const size_t row = (size_t)G * sizeof(double);
         bool ok = c->alloc_gather(nranks);
         for (int i = 0; i < 4 && ok; ++i) ok = hipHostMalloc(reinterpret_cast<void **>(&c->rowbuf_[i]), row, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->hgather_), (size_t)nranks * sizeof(double), hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->hgather_), (size_t)nranks * kBlockCap * sizeof(double), hipHostMallocDefault) == hipSuccess;
         if (!ok) { snprintf(msg, n, "allocation of the host staging buffers failed"); delete c; return nullptr; }
         return c;
     }
@@ -229,13 +239,14 @@ public:
 
     bool stream_ordered() const override { return false; }
 
-    int allgather_scalar(hipStream_t s) override
+    int allgather(hipStream_t s, double *buf, long count) override
     {
-        if (hip(hipMemcpyAsync(hgather_ + rank_, gather_ + rank_, sizeof(double), hipMemcpyDeviceToHost, s), "D2H scalar")) return -1;
+        if (count < 1 || count > kBlockCap) { snprintf(err_, sizeof err_, "all-gather of %ld doubles per rank", count); return -1; }
+        double *mine = hgather_ + (long)rank_ * count;
+        if (hip(hipMemcpyAsync(mine, buf + (long)rank_ * count, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s), "D2H")) return -1;
         if (hip(hipStreamSynchronize(s), "sync")) return -1;
-        const double mine = hgather_[rank_];
-        if (ag_(user_, mine, hgather_) != 0) { snprintf(err_, sizeof err_, "host all-gather callback failed"); return -1; }
-        if (hip(hipMemcpyAsync(gather_, hgather_, (size_t)nranks_ * sizeof(double), hipMemcpyHostToDevice, s), "H2D scalars")) return -1;
+        if (ag_(user_, mine, count, hgather_) != 0) { snprintf(err_, sizeof err_, "host all-gather callback failed"); return -1; }
+        if (hip(hipMemcpyAsync(buf, hgather_, (size_t)nranks_ * count * sizeof(double), hipMemcpyHostToDevice, s), "H2D")) return -1;
         return hip(hipStreamSynchronize(s), "sync");
     }
 

@@ -32,7 +32,8 @@
 //      workgroup, stored at partials[tile or block index];
 //   4. k_finish: thread t of 256 adds partials[t], partials[t+256], ... in that
 //      order, then steps 2 and 3 again;
-//   5. multi-GPU: the per-rank sums are added in rank order 0..P-1.
+//   5. multi-GPU: every rank's partials (step 3) are concatenated in rank order 0..P-1 by an
+//      all-gather, and step 4 runs over the concatenation on every rank.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -682,9 +683,8 @@ __global__ __launch_bounds__(64) void k_dot_strict(const double *__restrict__ v,
 //   what 4: as 1, for an iteration whose u update is deferred (sc->u_applied stays)
 //   what 2: q0   = sum ; q_init = q0 ; stop = rtol^2*q0                (cg.c:55)
 //   what 3: dot  = sum                                                 (stand-alone dot)
-// With `strict_src` the sum is taken from there instead of the partials: one value
-// (the strict-order result), or `nsrc` per-rank sums of a multi-rank solve, which are
-// added here in rank order 0..nsrc-1 (step 5 of the fast order).
+// With `strict_src` the sum is taken from there instead of the partials: one value (the
+// strict-order result), or `nsrc` values added in index order.
 __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long count,
                                                    const double *strict_src, int nsrc, Scalars *sc, int what,
                                                    double rtol, double *hist, long hist_cap)
@@ -750,18 +750,6 @@ __global__ void k_tree_sum(const double *vals, int count, double *out)
     for (int dist = 1; dist < count; dist *= 2)
         for (int r = 0; r + dist < count; r += 2 * dist) part[r] = part[r] + part[r + dist];
     *out = part[0];
-}
-
-// Fixed-order sum of block partials into one slot (local part of a multi-rank dot).
-__global__ __launch_bounds__(kBlock) void k_partial_sum(const double *partials, long count,
-                                                        const Scalars *sc, double *out)
-{
-    if (sc != nullptr && sc->done) return;
-    __shared__ double wave_slots[kWaves];
-    double acc = 0.0;
-    for (long k = threadIdx.x; k < count; k += kBlock) acc += partials[k];
-    const double s = block_sum(acc, wave_slots);
-    if (threadIdx.x == 0) *out = s;
 }
 
 // ---------------------------------------------------------------- set-up -----

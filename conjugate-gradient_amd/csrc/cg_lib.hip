@@ -321,6 +321,18 @@ void drop_graph(cg_ctx *c)
 // the fused schedules have no pending d update.  Every launch is
 // stream-ordered; nothing here synchronises, so the same code runs eagerly and
 // under stream capture.
+// Where a kernel puts the `npart` block partials of a dot product: the context's own array, or, in a
+// multi-rank context, this rank's slice of the all-gather buffer (see enqueue_dot_finish).
+int rank_partials(cg_ctx *c, double *own, long npart, double **out)
+{
+    if (c->nranks == 1 || c->reduce == CG_REDUCE_STRICT) { *out = own; return CG_OK; }
+    if (npart > cg::Comm::kBlockCap)
+        return fail(CG_ERR_ARG, "%ld tiles per rank exceed the all-gather buffer (%ld): use a larger CG_OPT_TILE_H",
+                    npart, cg::Comm::kBlockCap);
+    *out = c->comm->block_buf() + (long)c->rank * npart;
+    return CG_OK;
+}
+
 // Strict order, parallel evaluation: may the kernel that produces the operands hand over
 // approximate span sums (cg::exact::kSub products each)?  Needs 16-byte rows whose length is a
 // multiple of the span, so that spans never straddle rows; not used with the 2-D block layout.
@@ -382,13 +394,14 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
         }
         src = c->nranks > 1 ? c->comm->gather_buf() + (c->nranks - 1) : c->strict_slot;
     } else if (c->nranks > 1) {
-        // local fixed-order sum -> all ranks' sums (RCCL all-gather) -> rank-order sum
-        double *mine = c->comm->gather_buf() + c->rank;
-        hipLaunchKernelGGL(cg::k_partial_sum, dim3(1), dim3(kBlock), 0, s, partials, npart,
-                           (what < 2 || what == 4) ? c->sc : nullptr, mine);
-        CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
-        src = c->comm->gather_buf();                       // added in rank order by k_finish
-        nsrc = c->nranks;
+        // The kernels of a multi-rank context write their partials straight into this rank's slice of
+        // the all-gather buffer (rank_partials); one RCCL all-gather concatenates the ranks' slices in
+        // rank order, and k_finish adds the whole concatenation in its fixed order on every rank.
+        if (partials != c->comm->block_buf() + (long)c->rank * npart)
+            return fail(CG_ERR_STATE, "multi-rank dot product: partials are not in the all-gather buffer");
+        CGCHK(comm_rc(c, c->comm->allgather_block(s, npart)));
+        partials = c->comm->block_buf();
+        npart *= c->nranks;
     }
     hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, partials, npart, src, nsrc, c->sc, what, rtol,
                        c->hist, c->hist_cap);
@@ -438,7 +451,9 @@ int enqueue_lean_iteration(cg_ctx *c)
 {
     hipStream_t s = c->stream;
     const TileGeom t = ctx_geom(c);
-    double *p_dq = c->partials, *p_gg = c->partials + c->npart;
+    double *p_dq, *p_gg;
+    CGCHK(rank_partials(c, c->partials, t.ntiles, &p_dq));
+    CGCHK(rank_partials(c, c->partials + c->npart, t.ntiles, &p_gg));
     if (c->nranks > 1)      // g's boundary rows; d's halo rows are kept current locally
         CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
     const int in = c->dcur, out = c->dcur ^ 1;
@@ -479,9 +494,12 @@ int enqueue_iteration(cg_ctx *c, bool first)
         sched = CG_SCHED_FUSED_NOQ;       // d is materialised: stencil pass + in-place update pass, as there
     }
     const TileGeom t = ctx_geom(c);
-    double *p_dq = c->partials, *p_gg = c->partials + c->npart;
     const long nvec = c->count / t.vec;
     const int fb = flat_blocks(nvec, c->flat_blocks_opt);
+    const long npart_gg = (sched == CG_SCHED_FUSED_NOQ) ? t.ntiles : (long)fb;   // tiled or flat update kernel
+    double *p_dq, *p_gg;
+    CGCHK(rank_partials(c, c->partials, t.ntiles, &p_dq));
+    CGCHK(rank_partials(c, c->partials + c->npart, npart_gg, &p_gg));
 
     // ---- q = A d (+ d.q), with the pending d update folded in where scheduled
     StencilArgs a = base_args(c, t);
@@ -555,7 +573,6 @@ int enqueue_iteration(cg_ctx *c, bool first)
     else CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0, a.sub != nullptr));
 
     // ---- u += tau d ; g += tau q (+ g.g)
-    long npart_gg;
     double *gg_sub = nullptr;
     if (sched == CG_SCHED_FUSED_NOQ) {
         StencilArgs b = base_args(c, t);
@@ -565,14 +582,12 @@ int enqueue_iteration(cg_ctx *c, bool first)
         b.u = c->u; b.gw = c->g; b.partials = p_gg;
         b.sub = gg_sub = sub;
         launch_stencil<2, false>(t, b, s);
-        npart_gg = t.ntiles;
     } else {
         gg_sub = sub;
         if (t.vec == 2)
             hipLaunchKernelGGL(cg::k_update<2>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg, gg_sub);
         else
             hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg, gg_sub);
-        npart_gg = fb;
     }
     HIPCHK(hipGetLastError());
     CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0, gg_sub != nullptr));
@@ -1101,12 +1116,14 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     {
         const TileGeom t = ctx_geom(c);
         const int fb = flat_blocks(c->count / t.vec, c->flat_blocks_opt);
+        double *p0;
+        CGCHK(rank_partials(c, c->partials, fb, &p0));
         if (c->reduce != CG_REDUCE_STRICT) {
-            if (t.vec == 2) hipLaunchKernelGGL(cg::k_dot_partial<2>, dim3(fb), dim3(kBlock), 0, s, c->g, c->g, c->count, c->partials);
-            else hipLaunchKernelGGL(cg::k_dot_partial<1>, dim3(fb), dim3(kBlock), 0, s, c->g, c->g, c->count, c->partials);
+            if (t.vec == 2) hipLaunchKernelGGL(cg::k_dot_partial<2>, dim3(fb), dim3(kBlock), 0, s, c->g, c->g, c->count, p0);
+            else hipLaunchKernelGGL(cg::k_dot_partial<1>, dim3(fb), dim3(kBlock), 0, s, c->g, c->g, c->count, p0);
             HIPCHK(hipGetLastError());
         }
-        CGCHK(enqueue_dot_finish(c, c->g, c->g, c->partials, fb, 2, rtol));
+        CGCHK(enqueue_dot_finish(c, c->g, c->g, p0, fb, 2, rtol));
     }
     const int dcur_start = c->dcur, gcur_start = c->gcur;
     c->lean_pending = 0;

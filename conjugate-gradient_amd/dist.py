@@ -60,11 +60,15 @@ class RowTransport:
 
     def allgather(self, value):
         """[value of rank 0, ..., value of rank P-1], identical on every rank."""
+        return [float(v) for v in self.allgather_block([float(value)])]
+
+    def allgather_block(self, values):
+        """Concatenation over the ranks, in rank order, of each rank's equally long array of doubles."""
         torch, dist = self._torch, self._dist
-        mine = torch.tensor([float(value)], dtype=torch.float64)
-        out = [torch.empty(1, dtype=torch.float64) for _ in range(self.world)]
+        mine = torch.tensor(np.ascontiguousarray(values, dtype=np.float64))
+        out = [torch.empty(mine.numel(), dtype=torch.float64) for _ in range(self.world)]
         dist.all_gather(out, mine, group=self.group)
-        return [float(t.item()) for t in out]
+        return np.concatenate([t.numpy() for t in out])
 
 
 def _view(ptr, count):
@@ -88,9 +92,9 @@ def make_callbacks(transport):
             traceback.print_exc()
             return 1
 
-    def allgather(user, mine, out):
+    def allgather(user, mine, count, out):
         try:
-            vals = transport.allgather(mine)
+            vals = transport.allgather_block(_view(mine, count).copy())
             _view(out, len(vals))[:] = vals
             return 0
         except Exception:

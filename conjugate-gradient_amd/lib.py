@@ -77,7 +77,7 @@ SIGNATURES = {
 
 # callback prototypes of cg_comm_init_host (all pointers are host pointers)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)
-ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p)
 
 _lib = None
 

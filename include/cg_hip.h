@@ -197,11 +197,12 @@ int cg_comm_init(cg_ctx *ctx, const void *id128);
  *             rank-1's send_down, recv_bot from rank+1's send_up; `count` doubles
  *             each; a NULL pair means there is no neighbour on that side
  *             (utils.c:231-248).
- *   allgather: all[r] = rank r's `mine`, r = 0..nranks-1 (stands in for the
- *             MPI_Allreduce of utils.c:380; the sum is then formed in rank order). */
+ *   allgather: all[r*count .. r*count+count) = rank r's `mine[0..count)`, r = 0..nranks-1
+ *             (stands in for the MPI_Allreduce of utils.c:380: the ranks' partial sums are
+ *             concatenated in rank order and added in one fixed order on every rank). */
 typedef int (*cg_exchange_fn)(void *user, const double *send_up, const double *send_down,
                               double *recv_top, double *recv_bot, long count);
-typedef int (*cg_allgather_fn)(void *user, double mine, double *all);
+typedef int (*cg_allgather_fn)(void *user, const double *mine, long count, double *all);
 int cg_comm_init_host(cg_ctx *ctx, cg_exchange_fn exchange, cg_allgather_fn allgather, void *user);
 
 /* Transport self-test, collective over the ranks of the communicator: an all-gather of one
