@@ -10,7 +10,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-args="--steps 20 --warmup 6 --no-cpu-baseline $*"
+args="--steps 20 --warmup 6 --no-cpu-baseline --no-parity $*"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" $args > "$out/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$out/trace.log"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 "$root/bench.py" $args > "$out/fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$out/fetch.log"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -- python3 "$root/bench.py" $args > "$out/write.log" 2>&1 || { echo "write pass failed"; tail -5 "$out/write.log"; exit 1; }

@@ -36,7 +36,7 @@ def counter(sub, name):
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 short = lambda k: k.split("(")[0].replace("void ", "").replace("cg::", "")
 lines = [f"# rocprofv3 summary: {tag}", "",
-         "Command: `python3 bench.py --steps 20 --warmup 6 --no-cpu-baseline` under `rocprofv3 --kernel-trace --stats`, "
+         "Command: `python3 bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-parity` under `rocprofv3 --kernel-trace --stats`, "
          "then `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes.", "",
          "HBM bytes per launch = FETCH_SIZE x 1024 x 2 (gfx950 counts 128-B read requests as 64 B) + WRITE_SIZE x 1024.", "",
          "| kernel | calls | mean us | read MB/launch | write MB/launch | HBM GB/s (measured bytes) |", "|---|---|---|---|---|---|"]
