@@ -1085,14 +1085,13 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         HIPCHK(c->xs.reserve(c->count));
         if (c->xs.cap_chunks != before) drop_graph(c);      // captured nodes hold the old workspace
     }
-    // history buffer (set-up, outside the timed region)
-    if (c->hist_cap < max_iters) {
+    // history buffer (set-up, outside the timed region); at most 2^24 entries are kept
+    const long hist_want = max_iters < (1L << 24) ? max_iters : (1L << 24);
+    if (c->hist_cap < hist_want) {
         drop_graph(c);                                  // the graph's k_finish nodes hold the old pointer
         (void)hipFree(c->hist); c->hist = nullptr; c->hist_cap = 0;
-        if (max_iters > 0) {
-            HIPCHK(hipMalloc(&c->hist, (size_t)max_iters * sizeof(double)));
-            c->hist_cap = max_iters;
-        }
+        HIPCHK(hipMalloc(&c->hist, (size_t)hist_want * sizeof(double)));
+        c->hist_cap = hist_want;
     }
     // graph of the steady-state iteration body (set-up, outside the timed region)
     long glen = c->graph_iters;

@@ -164,9 +164,10 @@ int cg_solve(cg_ctx *ctx, long max_iters, double rtol, cg_result *out);
 /* Copy one of the context's vectors (rows*(n+1) doubles) to host memory.     */
 int cg_copy_out(cg_ctx *ctx, int which, double *host_dst, long count);
 /* Device pointer of one of the context's vectors (valid until cg_destroy or
- * the next cg_solve, which may swap d's two buffers).                        */
+ * the next cg_solve, which may move d and g to their other buffers).         */
 int cg_device_ptr(cg_ctx *ctx, int which, double **out);
-/* q1 of every iteration of the last solve (host pointer, up to `count`).     */
+/* q1 of every iteration of the last solve (host pointer, up to `count`; the first 2^24
+ * iterations of a solve are recorded).                                       */
 int cg_get_history(cg_ctx *ctx, double *host_dst, long count, long *written);
 
 /* ---- measurement ----------------------------------------------------------
