@@ -141,7 +141,7 @@ struct StencilArgs {
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
     Coef5 coef;                       // stencil coefficients
     int store_products;               // WRITE_Q kernels: store d*q (rounded) where q would go
-    double *sub;                      // MODE 0/1/2 with VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
+    double *sub;                      // VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
                                       // (MODE 2: g.g) of every aligned 128-element span (one wavefront's part of a row), at
                                       // sub[(r*G + column)/128] -- approximate chunk sums for the strict-order dot
 };
@@ -261,7 +261,8 @@ struct RawRow {
 // MODE 0: q = A d, partials of d.q                      (stencil entry points)
 // MODE 1: d' = beta*d - g, q = A d', partials of d'.q   (fused d-update)
 // MODE 2: q = A d recomputed, u += tau*d, g += tau*q, partials of g.g
-// MODE 3: MODE 1 without storing d' (reads only): partials of d'.q      (lean schedule, first pass)
+// MODE 3: MODE 1 without storing d' (reads only): partials of d'.q      (lean schedule, first pass;
+//         strict order: WRITE_Q with store_products keeps the rounded products d'*q)
 // MODE 4: d' = beta*d - g recomputed and stored, q = A d' recomputed, g' = g + tau*q stored to
 //         g_out, partials of g'.g'                                       (lean schedule, second pass)
 // MODE 5: MODE 4 plus the solution update of TWO iterations, u = (u + tau_prev*d) + tau*d':
@@ -439,6 +440,12 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     acc += row_own ? pg[v] * pg[v] : 0.0;   // halo rows carry g too here: not ours to count
                 }
                 BufIO<VEC>::store(row_rsrc_nn(a.g_out + m * G, row_own ? rowbytes : 0), off_main, pg);
+                if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
+                    double span = pg[0] * pg[0];
+                    span += pg[VEC - 1] * pg[VEC - 1];
+                    span = wave_sum(span);
+                    if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
+                }
                 if (MODE == 5) {
                     double pu[VEC];
 #pragma unroll
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     acc += mid[v] * qv[v];                             // q = 0 off the interior
                     span += mid[v] * qv[v];
                 }
-                if ((MODE == 0 || MODE == 1) && VEC == 2 && a.sub != nullptr) {    // wave-uniform
+                if (VEC == 2 && a.sub != nullptr) {                                // MODE 0, 1, 3; wave-uniform
                     span = wave_sum(span);
                     if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
                 }

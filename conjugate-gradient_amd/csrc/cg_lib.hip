@@ -274,8 +274,7 @@ struct cg_ctx {
     int effective_schedule() const
     {
         if (schedule >= 0) return schedule;
-        if (reduce == CG_REDUCE_STRICT) return CG_SCHED_FUSED_NOQ;                 // (stores the products d*q where q would go)
-        return lean_unavailable ? CG_SCHED_FUSED_NOQ : CG_SCHED_LEAN;
+        return lean_unavailable ? CG_SCHED_FUSED_NOQ : CG_SCHED_LEAN;    // strict order: the products d*q go where q would
     }
     void set_gcur(int k)
     {
@@ -464,10 +463,21 @@ int enqueue_lean_iteration(cg_ctx *c)
     a.d_bot = c->has_bot() ? c->halo_d[in][1] : nullptr;
     a.g_top = c->has_top() ? c->halo_g[0] : nullptr;
     a.g_bot = c->has_bot() ? c->halo_g[1] : nullptr;
-    launch_stencil<3, false>(t, a, s);
+    // Strict order: the pass also stores the rounded products d'*q (in the q array) and span sums of
+    // them; the sequential sum is then evaluated from the products alone.
+    const bool strict = c->reduce == CG_REDUCE_STRICT;
+    double *const sub = strict_sub(c, t);
+    a.sub = sub;
+    if (strict) {
+        a.q = c->q; a.store_products = 1;
+        launch_stencil<3, true>(t, a, s);
+    } else {
+        launch_stencil<3, false>(t, a, s);
+    }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, nullptr, nullptr, p_dq, t.ntiles, 0, 0.0));
+    CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, t.ntiles, 0, 0.0, sub != nullptr));
     StencilArgs b = a;
+    b.store_products = 0;
     b.partials = p_gg;
     b.d_out = c->d[out];
     b.d_top_out = c->has_top() ? c->halo_d[out][0] : nullptr;
@@ -478,7 +488,7 @@ int enqueue_lean_iteration(cg_ctx *c)
     if (with_u) launch_stencil<5, false>(t, b, s);
     else launch_stencil<4, false>(t, b, s);
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, nullptr, nullptr, p_gg, t.ntiles, with_u ? 1 : 4, 0.0));
+    CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, t.ntiles, with_u ? 1 : 4, 0.0, sub != nullptr));
     c->dcur = out;
     c->set_gcur(c->gcur ^ 1);
     c->lean_pending = with_u ? 0 : 1;
@@ -1057,8 +1067,6 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     if (!c || !out) return fail(CG_ERR_ARG, "cg_solve: NULL argument");
     if (max_iters < 0 || rtol < 0) return fail(CG_ERR_ARG, "cg_solve: max_iters and rtol must be >= 0");
     CGCHK(select_device(c->device));
-    if (c->reduce == CG_REDUCE_STRICT && c->effective_schedule() == CG_SCHED_LEAN)
-        return fail(CG_ERR_STATE, "the strict reduction order needs d and the products d*q in memory: CLASSIC, FUSED or FUSED_NOQ");
     if (c->nranks > 1 && !c->comm) return fail(CG_ERR_STATE, "multi-rank context without cg_comm_init");
     if (c->effective_schedule() == CG_SCHED_LEAN) CGCHK(lean_setup(c));   // may fall back to FUSED_NOQ (auto schedule only)
     const int sched = c->effective_schedule();

@@ -138,8 +138,6 @@ class CGSolver:
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
-            if schedule is None and reduce == _l.REDUCE_STRICT and self.schedule == _l.SCHED_LEAN:
-                schedule = -1                     # LEAN keeps neither d' nor q in memory: let the library pick
         if schedule is not None:
             self.set_option(_l.OPT_SCHEDULE, schedule)
             self.schedule = schedule if schedule >= 0 else None

@@ -102,11 +102,11 @@ typedef struct cg_ctx cg_ctx;
                                   (strict order: the rounded products d*q are stored where q would go) */
 #define CG_SCHED_LEAN     3    /* d' = beta*d - g recomputed in both passes instead of stored and re-read,
                                   u updated for two iterations at a time           : 56 B/point
-                                  (fast order only; needs a second gradient buffer) */
+                                  (needs a second gradient buffer; strict order: + 8 for the stored products d*q) */
 
 /* Option keys for cg_set_option. */
 #define CG_OPT_REDUCE      1   /* CG_REDUCE_*                        default FAST     */
-#define CG_OPT_SCHEDULE    2   /* CG_SCHED_*                         default LEAN (FUSED_NOQ when strict) */
+#define CG_OPT_SCHEDULE    2   /* CG_SCHED_*                         default LEAN */
 #define CG_OPT_TILE_H      3   /* rows per stencil tile, 0 = auto                     */
 #define CG_OPT_GRAPH_ITERS 4   /* iterations captured per hipGraph, 0 = no graph; default 10 */
 #define CG_OPT_XCD_REMAP   5   /* 1 = XCD-aware tile order (default), 0 = plain order  */
