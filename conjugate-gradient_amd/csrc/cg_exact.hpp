@@ -109,25 +109,52 @@ __device__ __forceinline__ int exponent_of(double s)
 }
 
 // Summary of kPerLane consecutive addends under the hypothesis "exponent e".
+// The per-element validity tests are folded into two running maxima and checked once:
+// |x| < 2^51 for every addend <=> max|x| < 2^51; no tie <=> max|x - rint(x)| != 0.5 (it never
+// exceeds 0.5); a NaN addend poisons D (v_max would skip it), which the final D == D catches.
 __device__ __forceinline__ Summary piece_summary(const double (&p)[kPerLane], int e)
 {
     const int sh = (e == kNoExp) ? 0 : 52 - e;
     Summary s = identity();
-    bool nz = false;
+    double amax = 0.0, fmaxv = 0.0, pmax = 0.0;
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         const double x = ldexp(p[i], sh);
         const double r = rint(x);
-        nz |= (p[i] != 0.0);
-        s.bad |= (!(fabs(x) < 0x1p51) || fabs(x - r) == 0.5) ? 1 : 0;
+        pmax = fmax(pmax, fabs(p[i]));
+        amax = fmax(amax, fabs(x));
+        fmaxv = fmax(fmaxv, fabs(x - r));
         s.D += r;
         s.mn = fmin(s.mn, s.D);
         s.mx = fmax(s.mx, s.D);
     }
-    if (!nz) return identity();                     // adding zeros leaves a non-zero accumulator unchanged
+    const bool nan = !(s.D == s.D) || !(pmax == pmax);
+    if (!nan && pmax == 0.0) return identity();     // adding zeros leaves a non-zero accumulator unchanged
+    s.bad = (nan || !(amax < 0x1p51) || fmaxv == 0.5 || e == kNoExp) ? 1 : 0;
     s.e = e;
-    if (e == kNoExp) s.bad = 1;
     return s;
+}
+
+// Ordered composition over the wavefront of summaries that share ONE hypothesis e (or are
+// identities): only D, mn, mx travel; flags and the exponent are combined by ballots.
+__device__ __forceinline__ Summary wave_compose_same_e(Summary cur, int e)
+{
+    const int lane = threadIdx.x & 63;
+    const bool any_bad = __ballot(cur.bad != 0) != 0ull;
+    const bool any_real = __ballot(cur.e != kAnyExp) != 0ull;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double nD = __shfl_down(cur.D, off, 64), nmn = __shfl_down(cur.mn, off, 64),
+                     nmx = __shfl_down(cur.mx, off, 64);
+        if ((lane & (2 * off - 1)) == 0) {
+            cur.mn = fmin(cur.mn, cur.D + nmn);
+            cur.mx = fmax(cur.mx, cur.D + nmx);
+            cur.D = cur.D + nD;
+        }
+    }
+    cur.bad = any_bad ? 1 : 0;
+    cur.e = any_real ? e : kAnyExp;
+    return cur;
 }
 
 // Product k of the sequence that is summed; w == nullptr means v already holds the rounded
@@ -159,6 +186,34 @@ __device__ __forceinline__ void product_pair(const double *__restrict__ v, const
     }
 }
 
+// The 16 products a lane fetches of one chunk (lane-interleaved: pair k of lane l starts at
+// base + k*128 + 2*l).  A chunk that lies wholly inside the arrays, with 16-byte aligned
+// operands, takes the straight-line path: eight (or sixteen) independent vector loads in
+// flight at once.  Everything else -- the last, partial chunk; unaligned arrays -- goes
+// through the guarded product_pair.  The choice is uniform over the wavefront.
+template <bool HAS_W>
+__device__ __forceinline__ void fetch_chunk(const double *__restrict__ v, const double *__restrict__ w, long base,
+                                            long count, bool vec, int lane, double (&p)[kPerLane])
+{
+    if (vec && base + kChunk <= count) {
+        xv2 a[kPerLane / 2], b[kPerLane / 2];
+#pragma unroll
+        for (int k = 0; k < kPerLane / 2; ++k) {
+            a[k] = __builtin_nontemporal_load(reinterpret_cast<const xv2 *>(v + base + k * 128 + 2 * lane));
+            if (HAS_W) b[k] = __builtin_nontemporal_load(reinterpret_cast<const xv2 *>(w + base + k * 128 + 2 * lane));
+        }
+#pragma unroll
+        for (int k = 0; k < kPerLane / 2; ++k) {
+            p[2 * k] = HAS_W ? a[k].x * b[k].x : a[k].x;
+            p[2 * k + 1] = HAS_W ? a[k].y * b[k].y : a[k].y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPerLane / 2; ++k)
+            product_pair(v, HAS_W ? w : nullptr, base + k * 128 + 2 * lane, count, vec, p[2 * k], p[2 * k + 1]);
+    }
+}
+
 // ---- A: approximate chunk sums ------------------------------------------------
 // `vec` = both arrays are 16-byte aligned (chunk bases are even, so pairs are aligned too).
 __global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v, const double *__restrict__ w,
@@ -167,15 +222,12 @@ __global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v,
     const int lane = threadIdx.x & 63;
     const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= nchunks) return;
-    const long base = c * kChunk;
+    double p[kPerLane];
+    if (w != nullptr) fetch_chunk<true>(v, w, c * kChunk, count, vec != 0, lane, p);
+    else fetch_chunk<false>(v, w, c * kChunk, count, vec != 0, lane, p);
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < kPerLane / 2; ++k) {
-        double p0, p1;
-        product_pair(v, w, base + k * 128 + 2 * lane, count, vec != 0, p0, p1);
-        acc += p0;
-        acc += p1;
-    }
+    for (int i = 0; i < kPerLane; ++i) acc += p[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) approx[c] = acc;
@@ -185,8 +237,13 @@ __global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v,
 // span of kSub consecutive products (one wavefront's worth of a row); eight of them make a
 // chunk sum, and pass A need not read the operands at all.
 constexpr int kSub = 128;
+// Two layouts of those span sums.  Linear: span i covers products [i*kSub, (i+1)*kSub).  By rows
+// (G > 0: the operands are `rows` rows of G products, G a multiple of kSub): the span that starts
+// at row m, column j sits at sub[(j/kSub)*rows + m], so that a wavefront walking down a column
+// strip writes consecutive doubles (scattered 8-byte stores, one per row a kilobyte apart, cost
+// the tiled kernels 20-35 % of their time).
 __global__ __launch_bounds__(256) void k_xs_from_sub(const double *__restrict__ sub, long nsub, long nchunks,
-                                                     double *__restrict__ approx)
+                                                     long G, long rows, double *__restrict__ approx)
 {
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
     if (c >= nchunks) return;
@@ -194,7 +251,13 @@ __global__ __launch_bounds__(256) void k_xs_from_sub(const double *__restrict__ 
 #pragma unroll
     for (int j = 0; j < kChunk / kSub; ++j) {
         const long i = c * (kChunk / kSub) + j;
-        acc += (i < nsub) ? sub[i] : 0.0;
+        if (i >= nsub) break;
+        if (G > 0) {
+            const long k = i * kSub, m = k / G, col = k - m * G;
+            acc += sub[(col / kSub) * rows + m];
+        } else {
+            acc += sub[i];
+        }
     }
     approx[c] = acc;
 }
@@ -252,6 +315,7 @@ __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, lo
 // ---- B: per-chunk integer summaries under the guessed exponent --------------------
 // Persistent wavefronts: each walks its own run of chunks and keeps the NEXT chunk's products in
 // flight while it summarises the current one.
+template <bool HAS_W>
 __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, const double *__restrict__ w,
                                                   long count, long nchunks, int vec, const double *__restrict__ approx,
                                                   const double *__restrict__ goff, Summary *__restrict__ out)
@@ -272,19 +336,19 @@ __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, 
     if (c >= cend) return;                          // whole wavefront leaves together
 
     double nxt[kPerLane];
-    auto fetch = [&](long chunk) {
-#pragma unroll
-        for (int k = 0; k < kPerLane / 2; ++k)
-            product_pair(v, w, chunk * kChunk + k * 128 + 2 * lane, count, vec != 0, nxt[2 * k], nxt[2 * k + 1]);
-    };
+    auto fetch = [&](long chunk) { fetch_chunk<HAS_W>(v, w, chunk * kChunk, count, vec != 0, lane, nxt); };
     fetch(c);
+    // guess of the accumulator at a chunk's start: scanned group offset + what precedes the chunk in its group
+    double guess_nxt = goff[c >> 6] + approx[c];
     for (; c < cend; ++c) {
         double cur[kPerLane];
 #pragma unroll
         for (int i = 0; i < kPerLane; ++i) cur[i] = nxt[i];
-        // guess of the accumulator at the chunk's start: scanned group offset + what precedes the chunk in its group
-        const int e = exponent_of(goff[c >> 6] + approx[c]);
-        if (c + 1 < cend) fetch(c + 1);                       // in flight during the work below
+        const int e = exponent_of(guess_nxt);
+        if (c + 1 < cend) {                                   // in flight during the work below
+            fetch(c + 1);
+            guess_nxt = goff[(c + 1) >> 6] + approx[c + 1];
+        }
 
 #pragma unroll
         for (int k = 0; k < kPerLane / 2; ++k) {
@@ -301,7 +365,7 @@ __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the next round's writes
         __builtin_amdgcn_wave_barrier();
 
-        const Summary s = wave_compose(piece_summary(p, e));
+        const Summary s = wave_compose_same_e(piece_summary(p, e), e);
         if (lane == 0) out[c] = s;
     }
 }
@@ -498,10 +562,12 @@ struct Workspace {
 // neighbouring rank produced) when start_dev is not null.  `result` may alias `start_dev`.
 // Stream-ordered; the workspace must have been reserved for `count`.  have_sub: ws.sub already
 // holds approximate sums of every aligned span of kSub products (written by the kernel that
-// produced v and w), so the operands are read once instead of twice.  Those sums only steer
+// produced v and w; sub_G > 0: in the by-rows layout of k_xs_from_sub), so the operands are read
+// once instead of twice.  Those sums only steer
 // the guesses; every guess is verified by the walk, so their accuracy affects speed, never bits.
 inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
-                    double *result, const double *start_dev = nullptr, bool have_sub = false)
+                    double *result, const double *start_dev = nullptr, bool have_sub = false, long sub_G = 0,
+                    long sub_rows = 0)
 {
     if (count <= 0) {
         hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, 0L, ws.chunks, 0L, ws.groups, 0L, ws.supers, 0L,
@@ -514,13 +580,16 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
     const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;   // (null w: v alone)
     if (have_sub)
         hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub,
-                           (count + kSub - 1) / kSub, nc, ws.approx);
+                           (count + kSub - 1) / kSub, nc, sub_G, sub_rows, ws.approx);
     else
         hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
     hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
     hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, start_dev);
     const unsigned cbp = cb < 1024u ? cb : 1024u;          // persistent: the four workgroups per CU that LDS allows
-    hipLaunchKernelGGL(k_xs_chunk, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
+    if (w != nullptr)
+        hipLaunchKernelGGL(k_xs_chunk<true>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
+    else
+        hipLaunchKernelGGL(k_xs_chunk<false>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
     hipLaunchKernelGGL(k_xs_group, dim3(sb), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup);
     hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, ws.supers, nsup,

@@ -70,6 +70,28 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;                         // valid in lane 0
 }
 
+// Sum over the wavefront in NO particular order, result valid in lane 63 only.  Data-parallel
+// primitives (row shifts inside each row of 16 lanes, then two row broadcasts) instead of LDS
+// permutes: a dozen and a half VALU instructions and nothing to wait for.  For approximate
+// sums only -- the documented reduction order of the dot products uses wave_sum.
+__device__ __forceinline__ double wave_sum_unordered(double v)
+{
+#define CG_DPP_ADD(CTRL, ROW_MASK)                                                                     \
+    do {                                                                                               \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true); \
+        v += __hiloint2double(hi_, lo_);                                                               \
+    } while (0)
+    CG_DPP_ADD(0x111, 0xf);           // row_shr:1   (lanes shifted in from outside the row read 0)
+    CG_DPP_ADD(0x112, 0xf);           // row_shr:2
+    CG_DPP_ADD(0x114, 0xf);           // row_shr:4
+    CG_DPP_ADD(0x118, 0xf);           // row_shr:8   -> lane 15 of each row holds the row's sum
+    CG_DPP_ADD(0x142, 0xa);           // row_bcast:15 into rows 1 and 3
+    CG_DPP_ADD(0x143, 0xc);           // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef CG_DPP_ADD
+    return v;
+}
+
 // Sum over the workgroup in the documented order; result valid in thread 0.
 __device__ __forceinline__ double block_sum(double v, double *wave_slots)
 {
@@ -142,8 +164,8 @@ struct StencilArgs {
     Coef5 coef;                       // stencil coefficients
     int store_products;               // WRITE_Q kernels: store d*q (rounded) where q would go
     double *sub;                      // VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
-                                      // (MODE 2: g.g) of every aligned 128-element span (one wavefront's part of a row), at
-                                      // sub[(r*G + column)/128] -- approximate chunk sums for the strict-order dot
+                                      // (MODE 2, 4, 5: g.g) of every aligned 128-element span (one wavefront's part of a
+                                      // row), at sub[(column/128)*rows + r] -- approximate sums for the strict-order dot
 };
 
 // Streaming accesses carry the non-temporal hint (global_load/store ... nt): every
@@ -429,8 +451,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
                     double span = pg[0] * pg[0];
                     span += pg[VEC - 1] * pg[VEC - 1];
-                    span = wave_sum(span);
-                    if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
+                    span = wave_sum_unordered(span);
+                    if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
                 }
             } else if (MODE == 4 || MODE == 5) {
                 double pg[VEC];
@@ -443,8 +465,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
                     double span = pg[0] * pg[0];
                     span += pg[VEC - 1] * pg[VEC - 1];
-                    span = wave_sum(span);
-                    if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
+                    span = wave_sum_unordered(span);
+                    if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
                 }
                 if (MODE == 5) {
                     double pu[VEC];
@@ -463,8 +485,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     span += mid[v] * qv[v];
                 }
                 if (VEC == 2 && a.sub != nullptr) {                                // MODE 0, 1, 3; wave-uniform
-                    span = wave_sum(span);
-                    if ((tid & 63) == 0 && row_own && j < G) a.sub[(m * G + j) >> 7] = span;
+                    span = wave_sum_unordered(span);
+                    if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
                 }
                 if (WRITE_Q) {
                     // q itself, or (strict order without a stored q) the rounded products d*q that the
@@ -527,9 +549,9 @@ __global__ __launch_bounds__(kBlock) void k_update(double *__restrict__ u, doubl
         // VEC 2: a wavefront's 64 lanes hold 128 consecutive elements starting at a multiple of 128:
         // their g.g goes to sub[] as approximate input for the strict-order dot product
         if (VEC == 2 && sub != nullptr) {
-            span = wave_sum(span);
+            span = wave_sum_unordered(span);
             const long first = (k - (threadIdx.x & 63)) * 2;
-            if ((threadIdx.x & 63) == 0 && first < count) sub[first >> 7] = span;
+            if ((threadIdx.x & 63) == 63 && first < count) sub[first >> 7] = span;
         }
     }
     const double s = block_sum(acc, wave_slots);

@@ -344,7 +344,7 @@ double *strict_sub(const cg_ctx *c, const TileGeom &t)
 }
 
 int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *partials, long npart,
-                       int what, double rtol, bool have_sub = false)
+                       int what, double rtol, int have_sub = 0)   // 1: xs.sub holds span sums, linear; 2: by rows
 {
     // Completes a dot product whose fast-order block partials are already in
     // `partials` (npart of them), or, in strict mode, recomputes it with the
@@ -386,7 +386,8 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
             double *slot = c->nranks > 1 ? c->comm->gather_buf() + c->rank : c->strict_slot;
             const double *seed = k > 0 ? c->comm->gather_buf() + (k - 1) : nullptr;
             if (k == c->rank) {
-                if (par) cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, slot, seed, have_sub);   // workspace reserved by cg_solve
+                if (par) cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, slot, seed, have_sub != 0,
+                                            have_sub == 2 ? c->G : 0, c->rows);   // workspace reserved by cg_solve
                 else hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, seed, slot);
             }
             if (c->nranks > 1) CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
@@ -475,7 +476,7 @@ int enqueue_lean_iteration(cg_ctx *c)
         launch_stencil<3, false>(t, a, s);
     }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, t.ntiles, 0, 0.0, sub != nullptr));
+    CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, t.ntiles, 0, 0.0, sub ? 2 : 0));
     StencilArgs b = a;
     b.store_products = 0;
     b.partials = p_gg;
@@ -488,7 +489,7 @@ int enqueue_lean_iteration(cg_ctx *c)
     if (with_u) launch_stencil<5, false>(t, b, s);
     else launch_stencil<4, false>(t, b, s);
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, t.ntiles, with_u ? 1 : 4, 0.0, sub != nullptr));
+    CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, t.ntiles, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
     c->dcur = out;
     c->set_gcur(c->gcur ^ 1);
     c->lean_pending = with_u ? 0 : 1;
@@ -579,8 +580,8 @@ int enqueue_iteration(cg_ctx *c, bool first)
         }
     }
     HIPCHK(hipGetLastError());
-    if (products) CGCHK(enqueue_dot_finish(c, c->q, nullptr, p_dq, t.ntiles, 0, 0.0, a.sub != nullptr));
-    else CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0, a.sub != nullptr));
+    if (products) CGCHK(enqueue_dot_finish(c, c->q, nullptr, p_dq, t.ntiles, 0, 0.0, a.sub ? 2 : 0));
+    else CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0, a.sub ? 2 : 0));
 
     // ---- u += tau d ; g += tau q (+ g.g)
     double *gg_sub = nullptr;
@@ -600,7 +601,8 @@ int enqueue_iteration(cg_ctx *c, bool first)
             hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg, gg_sub);
     }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0, gg_sub != nullptr));
+    CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0,
+                             gg_sub == nullptr ? 0 : (sched == CG_SCHED_FUSED_NOQ ? 2 : 1)));   // tiled kernel: by rows; flat: linear
 
     // ---- d = beta d - g: now (classic) or inside the next stencil kernel (fused)
     if (sched == CG_SCHED_CLASSIC) {
