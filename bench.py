@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: fp64 CG iterations/sec on the 16384^2 grid (BASELINE.json configs[2]/[3]).
+"""Headline benchmark: fp64 CG iterations/sec on the 16384^2 grid (one GPU, or row blocks over N GPUs).
 
   python bench.py --gpus N --steps K --warmup W
 

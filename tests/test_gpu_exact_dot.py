@@ -148,7 +148,7 @@ def test_strict_solve_matches_reference_at_speed(cg, oracle, golden, n, iters):
 
 
 def test_headline_16384_1000_strict_is_bit_identical_to_the_reference(cg, oracle, golden):
-    # BASELINE.json configs[2] in the reference's own summation order: 2.7e8-term dot products,
+    # The headline configuration in the reference's own summation order: 2.7e8-term dot products,
     # 1000 iterations, and every bit of q1, q_init and sum(u) equals what the reference printed
     # after 2314 s on a CPU core.
     rec = golden.get((16383, 1000, 1, 0.0))
@@ -180,7 +180,7 @@ def test_reference_multirank_summation_layout_reproduces_its_np_outputs(cg, gold
 
 
 def test_config_4096_to_1e8_is_bit_identical_to_the_reference_on_4_ranks(cg, golden):
-    # BASELINE.json configs[1]: 4096^2 to a relative residual of 1e-8.  The reference was run on 4 ranks
+    # The 4096^2 configuration, run to a relative residual of 1e-8.  The reference was run on 4 ranks
     # (a single rank would take hours): 6937 iterations.  Same summation layout here: same stopping
     # iteration, same last q1, bit for bit.
     rec = golden.get((4095, 100000, 4, 1e-8))

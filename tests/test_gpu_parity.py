@@ -316,7 +316,7 @@ def test_large_grid_properties(cg):
 
 
 def test_headline_16384_1000_against_reference_golden(cg, golden):
-    # BASELINE.json configs[2]: 16384^2, 1000 iterations.  The golden q1 / sum(u) come from the
+    # The headline configuration: 16384^2, 1000 iterations.  The golden q1 / sum(u) come from the
     # reference itself (one CPU core, ~40 minutes); the GPU run takes a few seconds.
     rec = golden.get((16383, 1000, 1, 0.0))
     if rec is None:
@@ -338,7 +338,7 @@ def test_headline_16384_1000_against_reference_golden(cg, golden):
 
 
 def test_config_4096_to_1e8_iteration_count(cg, golden):
-    # BASELINE.json configs[1]: 4096^2 to 1e-8 relative residual.  The reference (np=4) needs 6937
+    # The 4096^2 configuration, run to a relative residual of 1e-8.  The reference (np=4) needs 6937
     # iterations; near the threshold q1 falls by a few percent per iteration, so another summation
     # order may stop an iteration or two earlier or later.
     rec = golden.get((4095, 100000, 4, 1e-8))
