@@ -303,6 +303,20 @@ TileGeom ctx_geom(const cg_ctx *c)
     return t;
 }
 
+// Geometry of the kernels that produce d.q (MODE 0, 1, 3).  The lean schedule's first pass only
+// reads and is fastest with two workgroups per CU; a row block too short to give it that many
+// tiles (one rank's share of a multi-GPU run) gets tiles of half the height there: 83 instead of
+// 92 us at 2048 x 16384.  The g.g kernels keep `t`; each dot product has its own partials.
+TileGeom dq_geom(const cg_ctx *c, TileGeom t)
+{
+    if (c->tile_h == 0 && t.max_wgs > 0 && t.ntiles < 2 * t.max_wgs && t.tile_h >= 64) {
+        const long h = (t.tile_h + 1) / 2;
+        t.tile_h = (int)h;
+        t.ntiles = (long)t.nstrips * ((c->rows + h - 1) / h);
+    }
+    return t;
+}
+
 int comm_rc(const cg_ctx *c, int rc)
 {
     return rc == 0 ? CG_OK : fail(CG_ERR_COMM, "rank %d: %s", c->rank, c->comm->error());
@@ -450,14 +464,14 @@ int enqueue_uflush(cg_ctx *c, int pending, int newest_slot)
 int enqueue_lean_iteration(cg_ctx *c)
 {
     hipStream_t s = c->stream;
-    const TileGeom t = ctx_geom(c);
+    const TileGeom t = ctx_geom(c), tq = dq_geom(c, t);
     double *p_dq, *p_gg;
-    CGCHK(rank_partials(c, c->partials, t.ntiles, &p_dq));
+    CGCHK(rank_partials(c, c->partials, tq.ntiles, &p_dq));
     CGCHK(rank_partials(c, c->partials + c->npart, t.ntiles, &p_gg));
     if (c->nranks > 1)      // g's boundary rows; d's halo rows are kept current locally
         CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
     const int in = c->dcur, out = c->dcur ^ 1;
-    StencilArgs a = base_args(c, t);
+    StencilArgs a = base_args(c, tq);
     a.partials = p_dq;
     a.d_in = c->d[in]; a.g = c->g;
     a.d_top = c->has_top() ? c->halo_d[in][0] : nullptr;
@@ -471,13 +485,14 @@ int enqueue_lean_iteration(cg_ctx *c)
     a.sub = sub;
     if (strict) {
         a.q = c->q; a.store_products = 1;
-        launch_stencil<3, true>(t, a, s);
+        launch_stencil<3, true>(tq, a, s);
     } else {
-        launch_stencil<3, false>(t, a, s);
+        launch_stencil<3, false>(tq, a, s);
     }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, t.ntiles, 0, 0.0, sub ? 2 : 0));
+    CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, tq.ntiles, 0, 0.0, sub ? 2 : 0));
     StencilArgs b = a;
+    b.tile_h = t.tile_h; b.rt_total = (int)(t.ntiles / t.nstrips);      // the g.g geometry
     b.store_products = 0;
     b.partials = p_gg;
     b.d_out = c->d[out];
@@ -504,16 +519,16 @@ int enqueue_iteration(cg_ctx *c, bool first)
         if (!first) return enqueue_lean_iteration(c);
         sched = CG_SCHED_FUSED_NOQ;       // d is materialised: stencil pass + in-place update pass, as there
     }
-    const TileGeom t = ctx_geom(c);
+    const TileGeom t = ctx_geom(c), tq = dq_geom(c, t);
     const long nvec = c->count / t.vec;
     const int fb = flat_blocks(nvec, c->flat_blocks_opt);
     const long npart_gg = (sched == CG_SCHED_FUSED_NOQ) ? t.ntiles : (long)fb;   // tiled or flat update kernel
     double *p_dq, *p_gg;
-    CGCHK(rank_partials(c, c->partials, t.ntiles, &p_dq));
+    CGCHK(rank_partials(c, c->partials, tq.ntiles, &p_dq));
     CGCHK(rank_partials(c, c->partials + c->npart, npart_gg, &p_gg));
 
     // ---- q = A d (+ d.q), with the pending d update folded in where scheduled
-    StencilArgs a = base_args(c, t);
+    StencilArgs a = base_args(c, tq);
     a.partials = p_dq;
     a.q = c->q;
     double *const sub = strict_sub(c, t);                  // both dot products use it, one after the other
@@ -558,30 +573,30 @@ int enqueue_iteration(cg_ctx *c, bool first)
         a.g_bot = c->has_bot() ? c->halo_g[1] : nullptr;
         a.d_top_out = c->has_top() ? c->halo_d[out][0] : nullptr;
         a.d_bot_out = c->has_bot() ? c->halo_d[out][1] : nullptr;
-        if (sched == CG_SCHED_FUSED || products) launch_stencil<1, true>(t, a, s);
-        else launch_stencil<1, false>(t, a, s);
+        if (sched == CG_SCHED_FUSED || products) launch_stencil<1, true>(tq, a, s);
+        else launch_stencil<1, false>(tq, a, s);
         c->dcur = out;
     } else {
         a.d_in = c->d[c->dcur];
         a.d_top = c->has_top() ? c->halo_d[c->dcur][0] : nullptr;
         a.d_bot = c->has_bot() ? c->halo_d[c->dcur][1] : nullptr;
         if (sched == CG_SCHED_FUSED_NOQ && !products) {
-            launch_stencil<0, false>(t, a, s);
+            launch_stencil<0, false>(tq, a, s);
         } else if (!split) {
-            launch_stencil<0, true>(t, a, s);
+            launch_stencil<0, true>(tq, a, s);
         } else {
             StencilArgs in = a;                       // row tiles 1 .. rt_total-2: no halo row involved
             in.rt_first = 1;
-            launch_stencil<0, true>(t, in, s, a.rt_total - 2);
+            launch_stencil<0, true>(tq, in, s, a.rt_total - 2);
             HIPCHK(hipStreamWaitEvent(s, c->ev_halo, 0));
             StencilArgs ed = a;                       // first and last row tile, after the halos landed
             ed.edge_pair = 1;
-            launch_stencil<0, true>(t, ed, s, 2);
+            launch_stencil<0, true>(tq, ed, s, 2);
         }
     }
     HIPCHK(hipGetLastError());
-    if (products) CGCHK(enqueue_dot_finish(c, c->q, nullptr, p_dq, t.ntiles, 0, 0.0, a.sub ? 2 : 0));
-    else CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, t.ntiles, 0, 0.0, a.sub ? 2 : 0));
+    if (products) CGCHK(enqueue_dot_finish(c, c->q, nullptr, p_dq, tq.ntiles, 0, 0.0, a.sub ? 2 : 0));
+    else CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, tq.ntiles, 0, 0.0, a.sub ? 2 : 0));
 
     // ---- u += tau d ; g += tau q (+ g.g)
     double *gg_sub = nullptr;
@@ -1235,7 +1250,7 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     if (!c || !ms_per_launch || reps < 1) return fail(CG_ERR_ARG, "cg_time_kernel: bad arguments");
     CGCHK(select_device(c->device));                    // local kernels only: no communication, any rank may call it
     const int sched = c->effective_schedule();
-    const TileGeom t = ctx_geom(c);
+    const TileGeom t = ctx_geom(c), tq = dq_geom(c, t);
     hipStream_t s = c->stream;
     const long nvec = c->count / t.vec;
     const int fb = flat_blocks(nvec, c->flat_blocks_opt);
@@ -1250,11 +1265,11 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     double per_point = 0.0;
     auto launch = [&]() {
         if (sched == CG_SCHED_LEAN) {
-            StencilArgs a = base_args(c, t);
+            StencilArgs a = base_args(c, which == 0 ? tq : t);
             const int out = c->dcur ^ 1;
             a.partials = c->partials; a.d_in = c->d[c->dcur]; a.g = c->g;
             if (which == 0) {
-                launch_stencil<3, false>(t, a, s);
+                launch_stencil<3, false>(tq, a, s);
             } else {
                 a.partials = c->partials + c->npart; a.d_out = c->d[out]; a.g_out = c->g_buf[c->gcur ^ 1]; a.u = c->u;
                 if (which == 1) launch_stencil<4, false>(t, a, s);
@@ -1262,15 +1277,15 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
                 c->dcur = out; c->set_gcur(c->gcur ^ 1);
             }
         } else if (which == 0) {
-            StencilArgs a = base_args(c, t);
+            StencilArgs a = base_args(c, tq);
             a.partials = c->partials; a.q = c->q;
             if (sched == CG_SCHED_CLASSIC) {
                 a.d_in = c->d[c->dcur];
-                launch_stencil<0, true>(t, a, s);
+                launch_stencil<0, true>(tq, a, s);
             } else {
                 a.d_in = c->d[c->dcur]; a.g = c->g; a.d_out = c->d[c->dcur ^ 1];
-                if (sched == CG_SCHED_FUSED) launch_stencil<1, true>(t, a, s);
-                else launch_stencil<1, false>(t, a, s);
+                if (sched == CG_SCHED_FUSED) launch_stencil<1, true>(tq, a, s);
+                else launch_stencil<1, false>(tq, a, s);
                 c->dcur ^= 1;
             }
         } else if (which == 1) {
