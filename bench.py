@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=16383, help="argv n of the reference: grid side is n+1")
+    ap.add_argument("--n", "--grid-n", dest="n", type=int, default=16383,
+                    help="argv n of the reference: grid side is n+1 (--grid-n: the spelling that survives torch.distributed.run)")
     ap.add_argument("--schedule", choices=["classic", "fused", "fused_noq", "lean"], default="lean")
     ap.add_argument("--tile-h", type=int, default=0)
     ap.add_argument("--graph-iters", type=int, default=None,

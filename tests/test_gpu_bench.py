@@ -32,3 +32,19 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # the golden set has a single-rank record for this grid: the parity side run must reproduce it
     assert d["parity"]["bit_identical"] is True
+
+
+def test_bench_two_ranks_sharing_the_gpu():
+    # the N > 1 code path of the benchmark (row blocks, transport self-test, max-over-ranks timing), rehearsed
+    # with two processes on one GPU over the host-staged transport
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--grid-n", "2047", "--steps", "6", "--warmup", "2", "--share-gpu"],
+                       capture_output=True, text=True, timeout=400, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 1024 and d["config"]["transport"] == "host"
+    assert d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
