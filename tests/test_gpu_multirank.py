@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("schedule", ["classic", "fused", "fused_noq", "lean"])
-@pytest.mark.parametrize("world,n,iters", [(2, 255, 60), (4, 255, 60), (4, 1023, 120), (2, 20, 12)])
+@pytest.mark.parametrize("world,n,iters", [(2, 255, 60), (4, 255, 60), (4, 1023, 120), (2, 20, 12), (3, 20, 12), (7, 20, 12)])
 def test_multirank_matches_single_rank(oracle, tmp_path, schedule, world, n, iters):
     if (n + 1) % world:
         pytest.skip("grid side not divisible")
