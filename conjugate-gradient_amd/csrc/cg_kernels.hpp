@@ -19,6 +19,8 @@
 //   k_dot_strict       v.w with ONE accumulator in index order     utils.c:373-379
 //   k_finish           fixed-order sum of block partials + the scalar recurrences
 //                      tau = q0/(d.q), beta = q1/q0, q0 = q1       cg.c:62,:80,:89
+//   k_pack_block, k_tree_sum   the dot product in the layout of the reference on s*s ranks
+//                      (per-block sequential sums, MPI_Allreduce's combination)   utils.c:368-381,:408-417
 //   k_init_d, k_init_g problem set-up                              utils.c:319-350
 //
 // Reduction order of the fast (non-strict) dot products, fixed for a given grid
@@ -42,9 +44,9 @@ namespace cg {
 constexpr int kBlock = 256;           // 4 wavefronts of 64 lanes
 constexpr int kWaves = kBlock / 64;
 
-// Device-resident scalar state of one solve.  Only k_finish writes it; the other
-// kernels read tau / beta / done in their prologue, so the host never has to
-// look at a scalar inside the iteration loop (graph-capturable).
+// Device-resident scalar state of one solve.  Only k_finish writes it (and k_umark its
+// u_applied); the other kernels read tau / beta / done in their prologue, so the host
+// never has to look at a scalar inside the iteration loop (graph-capturable).
 struct Scalars {
     double q0;          // g.g of the previous iteration            (cg.c:55,:89)
     double q1;          // g.g of this iteration                    (cg.c:79)
