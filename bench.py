@@ -93,19 +93,33 @@ def parity_run(cg, s, n):
         return {"error": str(e)}
 
 
-def profiled_traffic(kernel, G, schedule):
+def source_id():
+    """Identity of the kernel sources this tree holds (sha256 over csrc/ and the C ABI header)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "conjugate-gradient_amd", "csrc")
+    for path in sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(ROOT, "include", "cg_hip.h")]:
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(kernel, G, schedule, reduce="fast"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/prof.sh), or None.
 
-    The counters cannot be collected from inside this process; the newest profiles/*_traffic.json taken
-    for the same grid and schedule is reported (FETCH_SIZE doubled, both counters x1024: gfx950 units).
+    The counters cannot be collected from inside this process; a profiles/*_traffic.json is reported only if
+    it was taken for the same grid, schedule and reduction order AND is stamped with the identity of the kernel
+    sources in this tree (FETCH_SIZE doubled, both counters x1024: gfx950 units) -- numbers measured on
+    other kernels are not this run's traffic.
     """
     best = None
     pdir = os.path.join(ROOT, "profiles")
+    sid = source_id()
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if name.endswith("_traffic.json"):
             try:
                 doc = json.load(open(os.path.join(pdir, name)))
-                if doc.get("grid") == G and doc.get("schedule") == schedule and kernel in doc.get("kernels", {}):
+                if doc.get("grid") == G and doc.get("schedule") == schedule and doc.get("reduce", "fast") == reduce and \
+                        doc.get("source_id") == sid and kernel in doc.get("kernels", {}):
                     best = doc["kernels"][kernel]["hbm_bytes_per_launch"]
             except Exception:
                 pass
@@ -203,12 +217,23 @@ def main():
 
     s.init_problem()
     if args.warmup > 0:
-        s.solve(args.warmup)                 # untimed: also captures the hipGraph
+        s.solve(args.warmup)                 # untimed
+        s.solve(args.steps)                  # untimed rehearsal of the timed call: captures the hipGraph for the buffer
+                                             # roles that call starts in, sizes the history buffer
     fence()
+    # The timed call continues the solve: K more iterations, each carrying one stencil application, both dot
+    # products and the three vector updates.  The lean schedule folds d = beta*d - g and every other u += tau*d
+    # into the following iteration's kernels, so the window holds the updates the warm-up's last iteration left
+    # owed and leaves its own last ones owed in turn -- exactly K of each operation either way.  What it takes to
+    # bring u and d up to date afterwards (needed once, when somebody reads them) is reported as flush_ms.
     t0 = time.perf_counter()
-    res = s.solve(args.steps)                # exactly K iterations, continuing the same solve
+    res = s.solve(args.steps)                # exactly K iterations
     fence()
     elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    s.sync_vectors()
+    fence()
+    flush_ms = 1e3 * (time.perf_counter() - t1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,7 +256,8 @@ def main():
                        "transport": transport, "parallelism": f"rowblocks{world}"},
             "hbm_gbs_per_gpu": bpp * rows * G * its / 1e9,
             "hbm_frac_of_peak": bpp * rows * G * its / 1e9 / HBM_PEAK_GBS,
-            "q1": res.q1, "iters_total": args.warmup + args.steps,
+            "q1": res.q1, "iters_total": args.warmup + 2 * args.steps, "flush_ms": flush_ms,
+            "source_id": source_id(),
         }
     # per-kernel roofline: HIP events on the solver's stream, this run, this GPU (rank 0's row block)
     if rank == 0:

@@ -9,8 +9,9 @@ from . import lib
 from .lib import (CGError, REDUCE_FAST, REDUCE_STRICT, SCHED_CLASSIC, SCHED_FUSED, SCHED_FUSED_NOQ, SCHED_LEAN,
                   VEC_U, VEC_G, VEC_D, VEC_Q, SCHED_BYTES_PER_POINT, SCHED_NAMES, device_count,
                   STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL)
-from .solver import CGSolver, DeviceVector, SolveResult, init_d, init_g, stencil, dot, axpy, xpay
+from .solver import (CGSolver, DeviceVector, SolveResult, init_d, init_g, stencil, dot, axpy, xpay, stencil_noalloc,
+                     verify_u)
 
 __all__ = ["lib", "CGError", "CGSolver", "DeviceVector", "SolveResult", "init_d", "init_g", "stencil", "dot",
-           "axpy", "xpay", "device_count", "REDUCE_FAST", "REDUCE_STRICT", "SCHED_CLASSIC", "SCHED_FUSED",
+           "axpy", "xpay", "stencil_noalloc", "verify_u", "device_count", "REDUCE_FAST", "REDUCE_STRICT", "SCHED_CLASSIC", "SCHED_FUSED",
            "SCHED_FUSED_NOQ", "SCHED_LEAN", "STRICT_AUTO", "STRICT_REPLAY", "STRICT_PARALLEL", "VEC_U", "VEC_G", "VEC_D", "VEC_Q", "SCHED_BYTES_PER_POINT", "SCHED_NAMES"]

@@ -51,6 +51,8 @@ public:
     virtual int exchange_rows(hipStream_t s, const double *base, long rows, long G, double *top_dst, double *bot_dst) = 0;
     // True if the calls above only enqueue stream work (hipGraph-capturable).
     virtual bool stream_ordered() const = 0;
+    // True if a one-rank communicator stands in for every peer (timing rehearsal): nothing can be agreed with anyone.
+    virtual bool self_only() const { return false; }
     // Self-test helper: move n doubles from src to dst through the transport's own
     // point-to-point primitives addressed to this rank itself (a no-op copy where the
     // transport has no such notion).  Lets a single process exercise send/receive.
@@ -58,6 +60,16 @@ public:
     {
         return hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
     }
+
+    // Single-rank rehearsal of the halo traffic: the block's first and last row are sent to this rank
+    // itself in one grouped send/receive, into scratch rows.  Transports without such a notion refuse.
+    virtual int rehearse_rows(hipStream_t, const double *, long, long)
+    {
+        snprintf(err_, sizeof err_, "this transport cannot rehearse the halo exchange");
+        return -1;
+    }
+    // Allocates the scratch rows of rehearse_rows (set-up time: never under stream capture).
+    virtual int prepare_rehearsal(long) { return rehearse_rows(nullptr, nullptr, 0, 0); }
 
 protected:
     bool alloc_gather(int nranks)
@@ -141,15 +153,19 @@ public:
     }
 
     // Collective over all ranks; the current HIP device must be this rank's GPU.
-    static RcclComm *create(const void *id128, int rank, int nranks, bool has_top, bool has_bot, char *msg, size_t n)
+    // self_only: a one-rank communicator stands in for every peer (timing rehearsal on one GPU): rows are
+    // sent to and received from this rank itself, the all-gathers run over this rank's slice alone.
+    static RcclComm *create(const void *id128, int rank, int nranks, bool has_top, bool has_bot, char *msg, size_t n,
+                            bool self_only = false)
     {
         RcclApi *api = RcclApi::get(msg, n);
         if (!api) return nullptr;
         RcclComm *c = new RcclComm;
         c->api_ = api; c->rank_ = rank; c->nranks_ = nranks; c->has_top_ = has_top; c->has_bot_ = has_bot;
+        c->self_only_ = self_only;
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
-        const ncclResult_t r = api->CommInitRank(&c->comm_, nranks, id, rank);
+        const ncclResult_t r = self_only ? api->CommInitRank(&c->comm_, 1, id, 0) : api->CommInitRank(&c->comm_, nranks, id, rank);
         if (r != ncclSuccess) {
             snprintf(msg, n, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, api->GetErrorString(r));
             c->comm_ = nullptr;
@@ -167,13 +183,16 @@ public:
     ~RcclComm() override
     {
         if (comm_) (void)api_->CommDestroy(comm_);
+        if (scratch_rows_) (void)hipFree(scratch_rows_);
     }
 
     bool stream_ordered() const override { return true; }
+    bool self_only() const override { return self_only_; }
 
     int allgather(hipStream_t s, double *buf, long count) override
     {
-        return check(api_->AllGather(buf + (long)rank_ * count, buf, (size_t)count, ncclDouble, comm_, s), "ncclAllGather");
+        double *mine = buf + (long)rank_ * count;
+        return check(api_->AllGather(mine, self_only_ ? mine : buf, (size_t)count, ncclDouble, comm_, s), "ncclAllGather");
     }
 
     // One grouped RCCL launch for the (up to) two sends and two receives.
@@ -181,14 +200,44 @@ public:
     {
         if (!has_top_ && !has_bot_) return 0;
         int rc = check(api_->GroupStart(), "ncclGroupStart");
+        const int below = self_only_ ? 0 : rank_ + 1, above = self_only_ ? 0 : rank_ - 1;
         if (rc == 0 && has_bot_) {
-            rc = check(api_->Send(base + (rows - 1) * G, (size_t)G, ncclDouble, rank_ + 1, comm_, s), "ncclSend(down)");
-            if (rc == 0) rc = check(api_->Recv(bot_dst, (size_t)G, ncclDouble, rank_ + 1, comm_, s), "ncclRecv(from below)");
+            rc = check(api_->Send(base + (rows - 1) * G, (size_t)G, ncclDouble, below, comm_, s), "ncclSend(down)");
+            if (rc == 0) rc = check(api_->Recv(bot_dst, (size_t)G, ncclDouble, below, comm_, s), "ncclRecv(from below)");
         }
         if (rc == 0 && has_top_) {
-            rc = check(api_->Send(base, (size_t)G, ncclDouble, rank_ - 1, comm_, s), "ncclSend(up)");
-            if (rc == 0) rc = check(api_->Recv(top_dst, (size_t)G, ncclDouble, rank_ - 1, comm_, s), "ncclRecv(from above)");
+            rc = check(api_->Send(base, (size_t)G, ncclDouble, above, comm_, s), "ncclSend(up)");
+            if (rc == 0) rc = check(api_->Recv(top_dst, (size_t)G, ncclDouble, above, comm_, s), "ncclRecv(from above)");
         }
+        const int rc2 = check(api_->GroupEnd(), "ncclGroupEnd");
+        return rc != 0 ? rc : rc2;
+    }
+
+    int prepare_rehearsal(long G) override
+    {
+        if (scratch_rows_ && scratch_len_ >= G) return 0;
+        if (scratch_rows_) (void)hipFree(scratch_rows_);
+        scratch_rows_ = nullptr; scratch_len_ = 0;
+        if (hipMalloc(&scratch_rows_, (size_t)(2 * G) * sizeof(double)) != hipSuccess) {
+            snprintf(err_, sizeof err_, "hipMalloc of the rehearsal rows failed");
+            return -1;
+        }
+        scratch_len_ = G;
+        return 0;
+    }
+
+    int rehearse_rows(hipStream_t s, const double *base, long rows, long G) override
+    {
+        if (!scratch_rows_ || scratch_len_ < G) {
+            snprintf(err_, sizeof err_, "rehearsal rows not prepared");
+            return -1;
+        }
+        const int self = self_only_ ? 0 : rank_;
+        int rc = check(api_->GroupStart(), "ncclGroupStart");
+        if (rc == 0) rc = check(api_->Send(base + (rows - 1) * G, (size_t)G, ncclDouble, self, comm_, s), "ncclSend(self, last row)");
+        if (rc == 0) rc = check(api_->Recv(scratch_rows_, (size_t)G, ncclDouble, self, comm_, s), "ncclRecv(self)");
+        if (rc == 0) rc = check(api_->Send(base, (size_t)G, ncclDouble, self, comm_, s), "ncclSend(self, first row)");
+        if (rc == 0) rc = check(api_->Recv(scratch_rows_ + G, (size_t)G, ncclDouble, self, comm_, s), "ncclRecv(self)");
         const int rc2 = check(api_->GroupEnd(), "ncclGroupEnd");
         return rc != 0 ? rc : rc2;
     }
@@ -196,8 +245,9 @@ public:
     int loopback(hipStream_t s, const double *src, double *dst, long n) override
     {
         int rc = check(api_->GroupStart(), "ncclGroupStart");
-        if (rc == 0) rc = check(api_->Send(src, (size_t)n, ncclDouble, rank_, comm_, s), "ncclSend(self)");
-        if (rc == 0) rc = check(api_->Recv(dst, (size_t)n, ncclDouble, rank_, comm_, s), "ncclRecv(self)");
+        const int self = self_only_ ? 0 : rank_;
+        if (rc == 0) rc = check(api_->Send(src, (size_t)n, ncclDouble, self, comm_, s), "ncclSend(self)");
+        if (rc == 0) rc = check(api_->Recv(dst, (size_t)n, ncclDouble, self, comm_, s), "ncclRecv(self)");
         const int rc2 = check(api_->GroupEnd(), "ncclGroupEnd");
         return rc != 0 ? rc : rc2;
     }
@@ -211,6 +261,9 @@ private:
     }
     RcclApi *api_ = nullptr;
     ncclComm_t comm_ = nullptr;
+    bool self_only_ = false;
+    double *scratch_rows_ = nullptr;      // rehearsal only
+    long scratch_len_ = 0;
 };
 
 // ------------------------------------------------------------- host-staged ---

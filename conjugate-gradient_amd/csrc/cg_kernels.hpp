@@ -61,6 +61,8 @@ struct Scalars {
     int pad;
     double tau_ring[8]; // tau of iteration i at [i & 7]: deferred u updates read them later
     long long u_applied;// iterations whose tau*d has been added into u (lean schedule defers them)
+    long long iter_base;// value of `iter` when the current solve began: a solve that continues the previous one
+                        // keeps counting (the ring and u_applied use absolute numbers), its history starts here
 };
 
 // ---------------------------------------------------------------- reductions --
@@ -133,10 +135,13 @@ __device__ __forceinline__ long xcd_remap(long b, long ntiles)
 
 // ------------------------------------------------------------------- stencil --
 
-// Coefficients of the five points the reference's kernels read (entries 1, 3, 4, 5, 7 of its
-// 3x3 integer array, cg.c:33), converted to double as utils.c:27-31 converts them per use.
-struct Coef5 {
-    double up, left, centre, right, down;
+// The 3x3 integer coefficient array of a stencil_struct (utils.h:3-7, cg.c:33), converted to double
+// as utils.c:27-31 converts its entries per use.  The reference's kernels read entries 1, 3, 4, 5, 7
+// (up, left, centre, right, down) only; the four corner entries are honoured here as well (`nine`
+// = any of them is non-zero), which the reference's own code never does.
+struct Coef9 {
+    double ul, up, ur, left, centre, right, dl, down, dr;
+    int nine;
 };
 
 struct StencilArgs {
@@ -157,13 +162,12 @@ struct StencilArgs {
     int nstrips;                      // column strips per row of tiles
     int tile_h;                       // rows per tile
     int remap;                        // 1 = XCD-aware tile order
-    // A launch may cover a subset of the block's row tiles (multi-GPU overlap: the
-    // tiles that need no halo row run while the halo rows are still in flight).
-    int rt_first;                     // first row tile of this launch
-    int rt_total;                     // row tiles in the whole block
-    int edge_pair;                    // 1 = this launch covers row tiles 0 and rt_total-1 only
+    // A launch covers rows [row_lo, row_hi) of the block in tiles of tile_h rows counted from row_lo
+    // (multi-GPU overlap: the rows next to a halo run in launches of their own, before or after the rest).
+    long row_lo, row_hi;
+    long part_base;                   // slot of this launch's first tile in `partials`
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
-    Coef5 coef;                       // stencil coefficients
+    Coef9 coef;                       // stencil coefficients
     int store_products;               // WRITE_Q kernels: store d*q (rounded) where q would go
     double *sub;                      // VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
                                       // (MODE 2, 4, 5: g.g) of every aligned 128-element span (one wavefront's part of a
@@ -198,7 +202,7 @@ template <> struct Pack<2> {
 
 // The five-point sum in the reference's order: up, left, centre, right, down,
 // added one by one to a zero accumulator (utils.c:25-31).
-__device__ __forceinline__ double five_point(const Coef5 &c, double up, double left, double centre,
+__device__ __forceinline__ double five_point(const Coef9 &c, double up, double left, double centre,
                                              double right, double down)
 {
     double acc = 0.0;
@@ -207,6 +211,25 @@ __device__ __forceinline__ double five_point(const Coef5 &c, double up, double l
     acc += c.centre * centre;
     acc += c.right * right;
     acc += c.down * down;
+    return acc;
+}
+
+// All nine entries, the same loop continued in array order 0..8: the row above left to right, the
+// point's own row, the row below.  With zero corners every extra term adds a (signed) zero, so the
+// value equals five_point's bit for bit; the kernels still take the five-term path then.
+__device__ __forceinline__ double nine_point(const Coef9 &c, double ul, double up, double ur, double left,
+                                             double centre, double right, double dl, double down, double dr)
+{
+    double acc = 0.0;
+    acc += c.ul * ul;
+    acc += c.up * up;
+    acc += c.ur * ur;
+    acc += c.left * left;
+    acc += c.centre * centre;
+    acc += c.right * right;
+    acc += c.dl * dl;
+    acc += c.down * down;
+    acc += c.dr * dr;
     return acc;
 }
 
@@ -315,13 +338,12 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     // b', b' + nwg, b' + 2 nwg, ... one after the other (b' = its XCD-aware slot).
     for (long lt = a.remap ? xcd_remap(blockIdx.x, nwg) : (long)blockIdx.x; lt < a.ntiles_launch; lt += nwg) {
     const long strip = lt % a.nstrips, lrt = lt / a.nstrips;
-    const long rt = a.edge_pair ? (lrt == 0 ? 0 : a.rt_total - 1) : a.rt_first + lrt;
-    const long tile = rt * a.nstrips + strip;         // index in the whole block: fixes the partial's slot
+    const long tile = a.part_base + lt;               // fixes the partial's slot
     const long G = a.G;
     const long c0 = strip * W;
     const long j = c0 + (long)tid * VEC;
-    const long r0 = rt * a.tile_h;
-    const long r1 = (r0 + a.tile_h < a.rows) ? r0 + a.tile_h : a.rows;
+    const long r0 = a.row_lo + lrt * a.tile_h;
+    const long r1 = (r0 + a.tile_h < a.row_hi) ? r0 + a.tile_h : a.row_hi;
     const int rowbytes = (int)(G * 8);
     const bool left_edge = (tid == 0) && (c0 > 0);
     const bool right_edge = (tid == kBlock - 1) && (c0 + W < G);
@@ -373,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
         }
     };
 
-    double up[VEC], mid[VEC], mid_u[VEC], mid_g[VEC], mid_dp[VEC], midL = 0.0, midR = 0.0;
+    double up[VEC], mid[VEC], mid_u[VEC], mid_g[VEC], mid_dp[VEC], midL = 0.0, midR = 0.0, upL = 0.0, upR = 0.0;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { up[v] = 0.0; mid[v] = 0.0; mid_u[v] = 0.0; mid_g[v] = 0.0; mid_dp[v] = 0.0; }
     double acc = 0.0;
@@ -438,7 +460,13 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 const double left = (v == 0) ? midL : mid[v - 1];
                 const double right = (v == VEC - 1) ? midR : mid[v + 1];
                 const bool in = row_in && (j + v >= 1) && (j + v <= G - 2);
-                qv[v] = in ? five_point(a.coef, up[v], left, mid[v], right, cur[v]) : 0.0;
+                if (a.coef.nine) {                                         // wave-uniform
+                    const double ul = (v == 0) ? upL : up[v - 1], ur = (v == VEC - 1) ? upR : up[v + 1];
+                    const double dl = (v == 0) ? curL : cur[v - 1], dr = (v == VEC - 1) ? curR : cur[v + 1];
+                    qv[v] = in ? nine_point(a.coef, ul, up[v], ur, left, mid[v], right, dl, cur[v], dr) : 0.0;
+                } else {
+                    qv[v] = in ? five_point(a.coef, up[v], left, mid[v], right, cur[v]) : 0.0;
+                }
             }
             if (MODE == 2) {
                 double pu[VEC], pg[VEC];
@@ -508,6 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
             for (int v = 0; v < VEC; ++v) {
                 up[v] = mid[v]; mid[v] = cur[v]; mid_u[v] = raw.u[v]; mid_g[v] = raw.g[v]; mid_dp[v] = raw.d[v];
             }
+            upL = midL; upR = midR;
             midL = curL; midR = curR;
         }
     }
@@ -714,18 +743,25 @@ __global__ __launch_bounds__(64) void k_dot_strict(const double *__restrict__ v,
 //   what 4: as 1, for an iteration whose u update is deferred (sc->u_applied stays)
 //   what 2: q0   = sum ; q_init = q0 ; stop = rtol^2*q0                (cg.c:55)
 //   what 3: dot  = sum                                                 (stand-alone dot)
+//   what 5: a solve that continues the previous one: q0 is the q1 the last iteration left (the same
+//           g.g, cg.c:55 and :89 hold the same value), so nothing is summed; q_init, stop and the
+//           history origin are set for the new solve
 // With `strict_src` the sum is taken from there instead of the partials: one value (the
 // strict-order result), or `nsrc` values added in index order.
+__device__ __forceinline__ double sum_partials(const double *partials, long count, double *wave_slots)
+{
+    double acc = 0.0;
+    for (long k = threadIdx.x; k < count; k += kBlock) acc += partials[k];
+    return block_sum(acc, wave_slots);
+}
+
 __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long count,
                                                    const double *strict_src, int nsrc, Scalars *sc, int what,
                                                    double rtol, double *hist, long hist_cap)
 {
     if ((what < 2 || what == 4) && sc->done) return;
     __shared__ double wave_slots[kWaves];
-    double acc = 0.0;
-    if (strict_src == nullptr)
-        for (long k = threadIdx.x; k < count; k += kBlock) acc += partials[k];
-    double s = block_sum(acc, wave_slots);
+    double s = sum_partials(partials, (strict_src == nullptr && what != 5) ? count : 0, wave_slots);
     if (threadIdx.x != 0) return;
     if (strict_src != nullptr) {
         s = strict_src[0];
@@ -739,8 +775,8 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
         sc->q1 = s;
         sc->beta = s / sc->q0;
         sc->q0 = s;
-        const long long it = sc->iter;
-        if (hist != nullptr && it < hist_cap) hist[it] = s;
+        const long long it = sc->iter, rel = it - sc->iter_base;
+        if (hist != nullptr && rel < hist_cap) hist[rel] = s;
         sc->iter = it + 1;
         if (what == 1) sc->u_applied = it + 1;
         if (sc->stop > 0.0 && s <= sc->stop) sc->done = 1;
@@ -750,10 +786,53 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
         sc->q_init = s;
         sc->stop = rtol * rtol * s;
         sc->iter = 0;
+        sc->iter_base = 0;
         sc->u_applied = 0;
+        sc->done = 0;
+    } else if (what == 5) {
+        sc->q_init = sc->q0;
+        sc->stop = rtol * rtol * sc->q0;
+        sc->iter_base = sc->iter;
         sc->done = 0;
     } else {
         sc->dot = s;
+    }
+}
+
+// The same fixed-order sum, written to a caller-supplied device location.
+__global__ __launch_bounds__(kBlock) void k_sum_to(const double *partials, long count, double *out)
+{
+    __shared__ double wave_slots[kWaves];
+    const double s = sum_partials(partials, count, wave_slots);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// Largest |u - x(1-x)y(1-y)| over a block of rows: the check against the closed-form solution of the
+// reference's problem (right-hand side of utils.c:334).  x = (double)i*h, y = (double)j*h, the product
+// evaluated left to right; a maximum does not depend on the order it is taken in.  One value per workgroup.
+__global__ __launch_bounds__(kBlock) void k_max_err(const double *__restrict__ u, long G, long row0, long rows,
+                                                    double h, double *__restrict__ block_max)
+{
+    __shared__ double wave_slots[kWaves];
+    const long total = rows * G;
+    const long stride = (long)gridDim.x * kBlock;
+    double m = 0.0;
+    for (long k = (long)blockIdx.x * kBlock + threadIdx.x; k < total; k += stride) {
+        const long r = k / G, j = k - r * G;
+        const double x = (double)(row0 + r) * h, y = (double)j * h;
+        const double e = fabs(u[k] - x * (1 - x) * y * (1 - y));
+        m = (e > m || e != e) ? e : m;                 // a NaN in u must surface, not vanish in the comparison
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(m, off, 64);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) wave_slots[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWaves; ++w) m = (wave_slots[w] > m || wave_slots[w] != wave_slots[w]) ? wave_slots[w] : m;
+        block_max[blockIdx.x] = m;
     }
 }
 

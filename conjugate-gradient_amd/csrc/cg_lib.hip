@@ -49,14 +49,18 @@ using cg::kBlock;
 using cg::Scalars;
 using cg::StencilArgs;
 
-// cg.c:33's coefficients at the five points the reference's kernels read.
-constexpr cg::Coef5 kPoisson5 = {-1.0, -1.0, 4.0, -1.0, -1.0};
+// cg.c:33's coefficients {0,-1,0,-1,4,-1,0,-1,0}.
+constexpr cg::Coef9 kPoisson9 = {0.0, -1.0, 0.0, -1.0, 4.0, -1.0, 0.0, -1.0, 0.0, 0};
 
-// Entries 1, 3, 4, 5, 7 of a 3x3 integer coefficient array (row-wise, as the reference's
-// stencil_struct holds it); entries 0, 2, 6, 8 are never read by the reference (utils.c:27-31).
-cg::Coef5 coef_from9(const int *s9)
+// A 3x3 integer coefficient array (row-wise, as the reference's stencil_struct holds it).  The
+// reference's kernels read entries 1, 3, 4, 5, 7 only (utils.c:27-31); the corner entries 0, 2, 6, 8
+// are honoured here too, and switch the kernels to the nine-term sum when any of them is non-zero.
+cg::Coef9 coef_from9(const int *s9)
 {
-    return cg::Coef5{(double)s9[1], (double)s9[3], (double)s9[4], (double)s9[5], (double)s9[7]};
+    cg::Coef9 c{(double)s9[0], (double)s9[1], (double)s9[2], (double)s9[3], (double)s9[4],
+                (double)s9[5], (double)s9[6], (double)s9[7], (double)s9[8], 0};
+    c.nine = (s9[0] != 0 || s9[2] != 0 || s9[6] != 0 || s9[8] != 0) ? 1 : 0;
+    return c;
 }
 
 constexpr int kMaxFlatBlocks = 512;       // two workgroups per CU: best measured HBM efficiency for mixed streams
@@ -171,14 +175,19 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
     return t;
 }
 
-// Launches the row tiles the arguments select: all of them (rt_first = 0), a
-// contiguous run starting at rt_first, or the first and last one (edge_pair).
+// Launches the tiled kernel over rows [row_lo, row_hi) of the block (default: all of it) in tiles of
+// t.tile_h rows counted from row_lo; the tiles' partial sums go to a0.partials[part_base ...].
+// Returns the number of tiles launched.
 template <int MODE, bool WRITE_Q>
-void launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, long row_tiles = -1)
+long launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, long row_lo = 0, long row_hi = -1,
+                    long part_base = 0)
 {
-    const long nrt = row_tiles >= 0 ? row_tiles : t.ntiles / t.nstrips;
-    if (nrt <= 0) return;
+    if (row_hi < 0) row_hi = a0.rows;
+    if (row_hi <= row_lo) return 0;
+    const long nrt = (row_hi - row_lo + t.tile_h - 1) / t.tile_h;
     StencilArgs a = a0;
+    a.tile_h = t.tile_h;
+    a.row_lo = row_lo; a.row_hi = row_hi; a.part_base = part_base;
     a.ntiles_launch = nrt * t.nstrips;
     // The read-only pass gets two workgroups per CU: measured 6.6 TB/s against 5.6 with one.
     const long cap = (MODE == 3) ? 2 * t.max_wgs : t.max_wgs;
@@ -199,6 +208,7 @@ void launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
         CG_LAUNCH(1, 2, true);
     }
 #undef CG_LAUNCH
+    return a.ntiles_launch;
 }
 
 } // namespace
@@ -206,6 +216,13 @@ void launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
 // =========================================================================
 // Context
 // =========================================================================
+
+struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    long len = 0;                         // iterations in the captured graph
+    int sched = -1, reduce = -1, dcur = -1, gcur = -1, pend = -1;   // state the capture began in
+    unsigned long stamp = 0;              // last use (least recently used slot is replaced)
+};
 
 struct cg_ctx {
     int device = 0;
@@ -223,6 +240,8 @@ struct cg_ctx {
     int prefetch_read = 0;                // read-only pass of the lean schedule; 0 = default
     long tile_wgs = 0;
     bool graph_explicit = false;          // the caller set CG_OPT_GRAPH_ITERS
+    int overlap = 1;                      // multi-rank lean schedule: halo exchange beside the interior rows
+    int rehearse = 0;                     // single rank with an RCCL communicator: issue the multi-rank traffic anyway
 
     // device state
     hipStream_t stream = nullptr;
@@ -237,13 +256,12 @@ struct cg_ctx {
     size_t padded_bytes = 0;              // size of each of those allocations
     double *d[kMaxSlots] = {nullptr};     // two direction buffers: the fused and lean schedules alternate
     int dcur = 0;                         // which of d[] holds the current direction
-    bool pending_dupdate = false;         // fused schedules: last d update not yet applied
     double *partials = nullptr;           // 2 * npart doubles (d.q | g.g)
     long npart = 0;
     Scalars *sc = nullptr;
     double *strict_slot = nullptr;
     cg::exact::Workspace xs;              // strict order, parallel evaluation
-    cg::Coef5 coef = kPoisson5;           // stencil coefficients (cg_set_stencil)
+    cg::Coef9 coef = kPoisson9;           // stencil coefficients (cg_set_stencil)
     int strict_impl = kStrictAuto;
     long strict_blocks = 0;               // s > 1: sum in the layout of the reference on s*s ranks
     double *pack[2] = {nullptr, nullptr}; // one rank's block of v and w, contiguous
@@ -254,27 +272,34 @@ struct cg_ctx {
     long hist_len = 0;
     bool q_valid = true;
 
+    // State a solve leaves behind for the next one.  The fused and lean schedules end a solve with the last
+    // d = beta*d - g (and, lean, at most one u += tau*d) still owed: a following cg_solve simply carries on
+    // (those updates ride on its first iteration, as they do between any two iterations); anything that
+    // looks at the vectors applies them first (materialise()).
+    bool pending_dupdate = false;         // the last d update has not been applied to d[dcur]
+    int lean_pending = 0;                 // lean schedule: iterations whose tau*d is not yet in u (0 or 1;
+                                          // the newest direction is d[dcur])
+    bool live = false;                    // q0 / beta on the device belong to the vectors' present state: a
+                                          // solve may continue from them without summing g.g again
+    bool needs_init = false;              // cg_time_kernel ran: the vectors are scratch until cg_init_problem
+
     // halo rows (multi-GPU).  *_top = the row above the block, *_bot = below.
     double *halo_d[kMaxSlots][2] = {{nullptr, nullptr}};               // [buffer][top/bot]
     double *halo_g[2] = {nullptr, nullptr};
     cg::Comm *comm = nullptr;
-    hipStream_t comm_stream = nullptr;    // halo exchange runs here, beside the interior stencil
+    hipStream_t comm_stream = nullptr;    // halo exchange runs here, beside the interior rows
     hipEvent_t ev_fork = nullptr, ev_halo = nullptr;
 
-    // captured iteration body
-    hipGraphExec_t graph = nullptr;
-    long graph_len = 0;                   // iterations in the captured graph
-    int graph_sched = -1, graph_reduce = -1, graph_dcur = -1, graph_gcur = -1;
-    // lean schedule, host view while enqueueing: iterations whose tau*d is not yet in u (0 or 1;
-    // the newest direction is d[dcur]).  Every second iteration applies its own and the previous one.
-    int lean_pending = 0;
+    // captured iteration bodies, one per starting state that has occurred
+    GraphSlot graphs[4];
+    unsigned long graph_clock = 0;
     Scalars *host_sc = nullptr;           // pinned read-back buffer
 
     bool lean_unavailable = false;        // not enough free HBM for the lean schedule's second gradient buffer
     int effective_schedule() const
     {
         if (schedule >= 0) return schedule;
-        return lean_unavailable ? CG_SCHED_FUSED_NOQ : CG_SCHED_LEAN;    // strict order: the products d*q go where q would
+        return lean_unavailable ? CG_SCHED_FUSED_NOQ : CG_SCHED_LEAN;
     }
     void set_gcur(int k)
     {
@@ -283,6 +308,7 @@ struct cg_ctx {
     }
     bool has_top() const { return row0 > 0; }
     bool has_bot() const { return row0 + rows < G; }
+    bool multi() const { return nranks > 1 || rehearse != 0; }      // dot products and halo rows go through the communicator
 };
 
 namespace {
@@ -324,21 +350,24 @@ int comm_rc(const cg_ctx *c, int rc)
 
 void drop_graph(cg_ctx *c)
 {
-    if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
-    c->graph_len = 0;
+    for (GraphSlot &g : c->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        g = GraphSlot();
+    }
 }
 
 // ---- one CG iteration, enqueued on the context's stream -------------------
 //
-// `first` = this is iteration 0 of a freshly initialised problem, for which
-// the fused schedules have no pending d update.  Every launch is
-// stream-ordered; nothing here synchronises, so the same code runs eagerly and
-// under stream capture.
+// Every launch is stream-ordered; nothing here synchronises with the host (the host-staged test
+// transport excepted), so the same code runs eagerly and under stream capture.
+//
 // Where a kernel puts the `npart` block partials of a dot product: the context's own array, or, in a
 // multi-rank context, this rank's slice of the all-gather buffer (see enqueue_dot_finish).
 int rank_partials(cg_ctx *c, double *own, long npart, double **out)
 {
-    if (c->nranks == 1 || c->reduce == CG_REDUCE_STRICT) { *out = own; return CG_OK; }
+    if (npart > c->npart)
+        return fail(CG_ERR_ARG, "%ld tiles exceed the %ld partial sums the context holds: use a larger CG_OPT_TILE_H", npart, c->npart);
+    if (!c->multi() || c->reduce == CG_REDUCE_STRICT) { *out = own; return CG_OK; }
     if (npart > cg::Comm::kBlockCap)
         return fail(CG_ERR_ARG, "%ld tiles per rank exceed the all-gather buffer (%ld): use a larger CG_OPT_TILE_H",
                     npart, cg::Comm::kBlockCap);
@@ -407,7 +436,7 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
             if (c->nranks > 1) CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
         }
         src = c->nranks > 1 ? c->comm->gather_buf() + (c->nranks - 1) : c->strict_slot;
-    } else if (c->nranks > 1) {
+    } else if (c->multi()) {
         // The kernels of a multi-rank context write their partials straight into this rank's slice of
         // the all-gather buffer (rank_partials); one RCCL all-gather concatenates the ranks' slices in
         // rank order, and k_finish adds the whole concatenation in its fixed order on every rank.
@@ -430,8 +459,18 @@ StencilArgs base_args(cg_ctx *c, const TileGeom &t)
     a.coef = c->coef;
     a.G = c->G; a.rows = c->rows; a.row0 = c->row0;
     a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = c->remap;
-    a.rt_first = 0; a.rt_total = (int)(t.ntiles / t.nstrips); a.edge_pair = 0;
     return a;
+}
+
+// The neighbours' boundary rows of g into g's halo rows (the fused and lean schedules keep d's halo rows
+// current locally, so g's rows are all that travels).  On a single rank that rehearses the multi-rank
+// traffic the same two rows are sent to the rank itself, into a scratch row.
+int exchange_g_rows(cg_ctx *c, hipStream_t on, double *gbuf)
+{
+    if (c->nranks > 1)
+        return comm_rc(c, c->comm->exchange_rows(on, gbuf, c->rows, c->G, gbuf - c->G, gbuf + c->count));
+    if (c->rehearse) return comm_rc(c, c->comm->rehearse_rows(on, gbuf, c->rows, c->G));
+    return CG_OK;
 }
 
 // u updates the lean schedule still owes when a solve ends (at most two): u += tau*d, oldest first.
@@ -452,8 +491,12 @@ int enqueue_uflush(cg_ctx *c, int pending, int newest_slot)
     return CG_OK;
 }
 
-// Steady-state iteration of the lean schedule.  State on entry: d[dcur] = d_{i-1}, g = g_i,
-// beta_i on the device; d_i = beta_i*d_{i-1} - g_i is never loaded back before it is used:
+// Rows at each end of a rank's block that the lean schedule's second pass computes in launches of their own,
+// ahead of the rest, so that the new gradient's boundary rows can travel while the other rows are computed.
+constexpr long kEdgeRows = 8;
+
+// Steady-state iteration of the lean schedule.  State on entry: d[dcur] = d_{i-1}, g = g_i (halo rows
+// included), beta_i on the device; d_i = beta_i*d_{i-1} - g_i is never loaded back before it is used:
 //   pass 1 (reads d_{i-1}, g_i):            d_i on the fly, partials of d_i . A d_i       -> tau_i
 //   pass 2 (reads d_{i-1}, g_i once more):  d_i again -> the other direction buffer,
 //                                           g_{i+1} = g_i + tau_i*A d_i -> other gradient buffer,
@@ -461,15 +504,26 @@ int enqueue_uflush(cg_ctx *c, int pending, int newest_slot)
 //   every second pass 2 also:               u = (u + tau_{i-1}*d_{i-1}) + tau_i*d_i  (both operands are at hand)
 // 16 + 32 + 16/2 = 56 B per point against 64 for the schedule that stores d' between the passes, and
 // pass 1 is a pure read stream.  Same arithmetic in the same order: bit-identical vectors.
+// Several ranks: pass 2 does the block's first and last kEdgeRows rows first; their g_{i+1} rows then go
+// to the neighbours on the communication stream while the other rows are computed (the reference's
+// post - interior - wait - edges of utils.c:45-104, with the edges first because it is their OUTPUT that
+// travels here); the stream joins before the iteration ends, so every iteration is self-contained.
 int enqueue_lean_iteration(cg_ctx *c)
 {
     hipStream_t s = c->stream;
     const TileGeom t = ctx_geom(c), tq = dq_geom(c, t);
+    const bool overlap = c->multi() && c->overlap && c->rows >= 4 * kEdgeRows;
+    TileGeom ti = t;                                       // pass 2, rows between the edge strips
+    long n_gg = t.ntiles;
+    if (overlap) {
+        ti = tile_geom(c->G, c->rows - 2 * kEdgeRows, true, c->tile_h);
+        ti.contig = 1; ti.pf = t.pf; ti.max_wgs = t.max_wgs;
+        for (int m = 0; m < 6; ++m) ti.pf_mode[m] = t.pf_mode[m];
+        n_gg = 2 * (long)t.nstrips + ti.ntiles;
+    }
     double *p_dq, *p_gg;
     CGCHK(rank_partials(c, c->partials, tq.ntiles, &p_dq));
-    CGCHK(rank_partials(c, c->partials + c->npart, t.ntiles, &p_gg));
-    if (c->nranks > 1)      // g's boundary rows; d's halo rows are kept current locally
-        CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
+    CGCHK(rank_partials(c, c->partials + c->npart, n_gg, &p_gg));
     const int in = c->dcur, out = c->dcur ^ 1;
     StencilArgs a = base_args(c, tq);
     a.partials = p_dq;
@@ -492,7 +546,6 @@ int enqueue_lean_iteration(cg_ctx *c)
     HIPCHK(hipGetLastError());
     CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, tq.ntiles, 0, 0.0, sub ? 2 : 0));
     StencilArgs b = a;
-    b.tile_h = t.tile_h; b.rt_total = (int)(t.ntiles / t.nstrips);      // the g.g geometry
     b.store_products = 0;
     b.partials = p_gg;
     b.d_out = c->d[out];
@@ -501,21 +554,41 @@ int enqueue_lean_iteration(cg_ctx *c)
     b.g_out = c->g_buf[c->gcur ^ 1];
     b.u = c->u;
     const bool with_u = c->lean_pending == 1;             // the previous iteration's u update is outstanding: do both
-    if (with_u) launch_stencil<5, false>(t, b, s);
-    else launch_stencil<4, false>(t, b, s);
+    auto pass2 = [&](const TileGeom &tg, long lo, long hi, long base) -> long {
+        return with_u ? launch_stencil<5, false>(tg, b, s, lo, hi, base) : launch_stencil<4, false>(tg, b, s, lo, hi, base);
+    };
+    if (overlap) {
+        TileGeom te = t;                                   // one tile per strip at each end
+        te.tile_h = (int)kEdgeRows;
+        pass2(te, 0, kEdgeRows, 0);
+        pass2(te, c->rows - kEdgeRows, c->rows, t.nstrips);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
+        CGCHK(exchange_g_rows(c, c->comm_stream, b.g_out));
+        HIPCHK(hipEventRecord(c->ev_halo, c->comm_stream));
+        pass2(ti, kEdgeRows, c->rows - kEdgeRows, 2 * (long)t.nstrips);
+    } else {
+        pass2(t, 0, c->rows, 0);
+        if (c->multi()) CGCHK(exchange_g_rows(c, s, b.g_out));
+    }
     HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, t.ntiles, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
+    CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
+    if (overlap) HIPCHK(hipStreamWaitEvent(s, c->ev_halo, 0));         // join: the halo rows have landed
     c->dcur = out;
     c->set_gcur(c->gcur ^ 1);
     c->lean_pending = with_u ? 0 : 1;
     return CG_OK;
 }
 
+// An iteration of the classic / fused schedules, or (`first`) the iteration that starts from a materialised
+// d -- no d update owed -- in any schedule; the lean schedule runs it in the fused_noq form.
 int enqueue_iteration(cg_ctx *c, bool first)
 {
     hipStream_t s = c->stream;
     int sched = c->effective_schedule();
-    if (sched == CG_SCHED_LEAN) {
+    const bool lean = sched == CG_SCHED_LEAN;
+    if (lean) {
         if (!first) return enqueue_lean_iteration(c);
         sched = CG_SCHED_FUSED_NOQ;       // d is materialised: stencil pass + in-place update pass, as there
     }
@@ -539,18 +612,19 @@ int enqueue_iteration(cg_ctx *c, bool first)
     a.store_products = products ? 1 : 0;
     const bool fuse = (sched != CG_SCHED_CLASSIC) && !first;
     bool split = false;                   // interior tiles run beside the halo exchange
-    if (c->nranks > 1) {
+    const long nrt = tq.ntiles / tq.nstrips;               // row tiles of the d.q geometry
+    if (c->multi()) {
         // Row halos: the fused kernel needs the neighbours' boundary rows of g (d's
         // halo rows are kept current locally); the plain kernel needs those of d.
         if (fuse) {
             // beta (from the all-gather that has just completed on s) gates every tile, so
             // there is nothing to overlap with: the exchange simply precedes the kernel.
-            CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->g, c->rows, c->G, c->halo_g[0], c->halo_g[1])));
-        } else if (sched == CG_SCHED_CLASSIC) {
+            CGCHK(exchange_g_rows(c, s, c->g));
+        } else if (sched == CG_SCHED_CLASSIC && c->nranks > 1) {
             // The reference's structure (utils.c:45-62): post the exchange, run the
             // stencil on the rows that need no halo, wait, then do the edge rows.  The
             // exchange goes to its own stream; events express the fork and the join.
-            split = a.rt_total >= 3;
+            split = nrt >= 3;
             if (split) {
                 HIPCHK(hipEventRecord(c->ev_fork, s));
                 HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
@@ -562,7 +636,8 @@ int enqueue_iteration(cg_ctx *c, bool first)
                                                         c->halo_d[c->dcur][1])));
             }
         }
-        // (first iteration of a fused schedule: d0's halo rows are a closed form, set at init)
+        // (first iteration of a fused schedule: d's halo rows are current -- a closed form at set-up,
+        //  exchanged when a pending d update was applied)
     }
     if (fuse) {
         const int in = c->dcur, out = c->dcur ^ 1;
@@ -585,13 +660,12 @@ int enqueue_iteration(cg_ctx *c, bool first)
         } else if (!split) {
             launch_stencil<0, true>(tq, a, s);
         } else {
-            StencilArgs in = a;                       // row tiles 1 .. rt_total-2: no halo row involved
-            in.rt_first = 1;
-            launch_stencil<0, true>(tq, in, s, a.rt_total - 2);
+            // row tiles 1 .. nrt-2 touch no halo row; the first and the last one wait for the halos
+            const long h = tq.tile_h;
+            launch_stencil<0, true>(tq, a, s, h, (nrt - 1) * h, tq.nstrips);
             HIPCHK(hipStreamWaitEvent(s, c->ev_halo, 0));
-            StencilArgs ed = a;                       // first and last row tile, after the halos landed
-            ed.edge_pair = 1;
-            launch_stencil<0, true>(tq, ed, s, 2);
+            launch_stencil<0, true>(tq, a, s, 0, h, 0);
+            launch_stencil<0, true>(tq, a, s, (nrt - 1) * h, c->rows, (nrt - 1) * tq.nstrips);
         }
     }
     HIPCHK(hipGetLastError());
@@ -616,6 +690,9 @@ int enqueue_iteration(cg_ctx *c, bool first)
             hipLaunchKernelGGL(cg::k_update<1>, dim3(fb), dim3(kBlock), 0, s, c->u, c->g, c->d[c->dcur], c->q, c->count, c->sc, p_gg, gg_sub);
     }
     HIPCHK(hipGetLastError());
+    // The lean schedule's iterations expect g's halo rows in place when they begin (each one sends its
+    // own new rows off before it ends): the iteration that leads into them does the same.
+    if (lean && c->multi()) CGCHK(exchange_g_rows(c, s, c->g));
     CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0,
                              gg_sub == nullptr ? 0 : (sched == CG_SCHED_FUSED_NOQ ? 2 : 1)));   // tiled kernel: by rows; flat: linear
 
@@ -652,6 +729,20 @@ int flush_pending_dupdate(cg_ctx *c)
     return CG_OK;
 }
 
+// Bring u and d to the state the reference's loop leaves them in after the iterations run so far (cg.c:63-69,
+// :81-87): apply the u and d updates the last solve left owed.  With several ranks the d update ends with a
+// halo exchange, so this is a collective step there: every rank reaches it through the same call.
+int materialise(cg_ctx *c)
+{
+    if (!c->pending_dupdate && c->lean_pending == 0) return CG_OK;
+    CGCHK(select_device(c->device));
+    CGCHK(enqueue_uflush(c, c->lean_pending, c->dcur));
+    c->lean_pending = 0;
+    CGCHK(flush_pending_dupdate(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CG_OK;
+}
+
 // Lean schedule set-up: the second gradient buffer (with its guard rows, zero-filled) is
 // allocated on first use.  Without enough free HBM an automatically chosen schedule falls
 // back to FUSED_NOQ; an explicitly requested LEAN fails.
@@ -674,15 +765,32 @@ int lean_setup(cg_ctx *c)
     return CG_OK;
 }
 
-// Capture `len` iterations (none of them the first) into a graph.  Fused
-// schedules swap d's buffers every iteration, so len is forced even and the
-// buffer roles are the same at every replay.
-int build_graph(cg_ctx *c, long len)
+// The captured graph of `len` steady-state iterations that starts from the context's present buffer
+// roles, or nullptr.  Fused schedules swap d's buffers every iteration (lean: also g's, and the paired u
+// update has period 2), so len is forced even and the roles are the same at every replay.
+GraphSlot *find_graph(cg_ctx *c, int sched)
 {
-    drop_graph(c);
+    for (GraphSlot &g : c->graphs)
+        if (g.exec && g.sched == sched && g.reduce == c->reduce && g.dcur == c->dcur && g.gcur == c->gcur &&
+            g.pend == c->lean_pending) {
+            g.stamp = ++c->graph_clock;
+            return &g;
+        }
+    return nullptr;
+}
+
+int build_graph(cg_ctx *c, long len, GraphSlot **out)
+{
+    *out = nullptr;
     const int sched = c->effective_schedule();
     if (sched != CG_SCHED_CLASSIC && (len & 1)) ++len;
-    // (lean: direction buffer, gradient buffer and the paired u update all have period 2)
+    GraphSlot *slot = &c->graphs[0];
+    for (GraphSlot &g : c->graphs) {
+        if (!g.exec) { slot = &g; break; }
+        if (g.stamp < slot->stamp) slot = &g;
+    }
+    if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+    *slot = GraphSlot();
     hipGraph_t graph = nullptr;
     const int dcur0 = c->dcur, gcur0 = c->gcur, pend0 = c->lean_pending;
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -694,14 +802,17 @@ int build_graph(cg_ctx *c, long len)
     c->lean_pending = pend0;
     if (rc != CG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(CG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    e = hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) { c->graph = nullptr; return fail(CG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-    c->graph_len = len;
-    c->graph_sched = sched;
-    c->graph_reduce = c->reduce;
-    c->graph_dcur = dcur0;
-    c->graph_gcur = gcur0;
+    if (e != hipSuccess) { slot->exec = nullptr; return fail(CG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    slot->len = len;
+    slot->sched = sched;
+    slot->reduce = c->reduce;
+    slot->dcur = dcur0;
+    slot->gcur = gcur0;
+    slot->pend = pend0;
+    slot->stamp = ++c->graph_clock;
+    *out = slot;
     return CG_OK;
 }
 
@@ -810,7 +921,6 @@ int cg_stencil9(int device, const int *stencil9, long G, long row0, long rows, c
     a.q = q; a.partials = sc->partials; a.sc = nullptr;
     a.coef = coef_from9(stencil9);
     a.G = G; a.rows = rows; a.row0 = row0; a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = 1;
-    a.rt_first = 0; a.rt_total = (int)(t.ntiles / t.nstrips); a.edge_pair = 0;
     launch_stencil<0, true>(t, a, sc->stream);
     HIPCHK(hipGetLastError());
     if (dq_host) {
@@ -889,6 +999,95 @@ int cg_xpay(int device, long count, double b, double *d, const double *g)
     return CG_OK;
 }
 
+int cg_verify_u(int device, long n, long row0, long rows, const double *u, double sum_start, double *sum_u_host,
+                double *max_err_host)
+{
+    if (!u || n < 2 || rows < 1 || row0 < 0 || row0 + rows > n + 1)
+        return fail(CG_ERR_ARG, "cg_verify_u: need n >= 2 and 0 <= row0 < row0+rows <= n+1");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    const long G = n + 1, count = rows * G;
+    if (sum_u_host) {
+        // the sequential sum of utils.c:372-379 with the products replaced by the elements themselves
+        if (use_parallel_strict(kStrictAuto, count)) {
+            HIPCHK(sc->xs.reserve(count));
+            cg::exact::enqueue(sc->stream, sc->xs, u, nullptr, count, sum_start, sc->slot);
+        } else {
+            hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, sc->stream, u, (const double *)nullptr, count, sum_start,
+                               (const double *)nullptr, sc->slot);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sum_u_host, sc->slot, sizeof(double), hipMemcpyDeviceToHost, sc->stream));
+    }
+    if (max_err_host) {
+        const int fb = flat_blocks(count, 0);
+        const double h = (double)1 / (double)n;         // utils.c:323
+        hipLaunchKernelGGL(cg::k_max_err, dim3(fb), dim3(kBlock), 0, sc->stream, u, G, row0, rows, h, sc->partials);
+        HIPCHK(hipGetLastError());
+        std::vector<double> bm((size_t)fb);
+        HIPCHK(hipMemcpyAsync(bm.data(), sc->partials, (size_t)fb * sizeof(double), hipMemcpyDeviceToHost, sc->stream));
+        HIPCHK(hipStreamSynchronize(sc->stream));
+        double m = 0.0;
+        for (double v : bm) m = (v > m || v != v) ? v : m;
+        *max_err_host = m;
+    }
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
+// ---- the entry point that allocates nothing --------------------------------------------------------
+// cg_stencil's kernels with their scratch (one partial sum per tile) in a file-scope device array instead
+// of memory the library allocates: nothing here calls hipMalloc, hipFree, a stream or event constructor
+// or any other allocating routine, and nothing synchronises, so the call may sit inside a stream capture.
+// Each GPU holds its own copy of the array until the process ends; its address on a device is looked up
+// once, with that device current, and only that address is ever handed to kernels.
+constexpr long kStaticPartials = 1L << 16;               // tiles of one call: 512 KiB of partial sums
+static __device__ __align__(256) double scratch[kStaticPartials];
+static double *g_static_ptr[kMaxDevices] = {nullptr};
+static std::mutex g_static_mu;
+
+int cg_stencil_noalloc(int device, long G, long row0, long rows, const double *d, const double *top,
+                       const double *bot, double *q, double *dq_dev, void *stream)
+{
+    static const int poisson9[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};      // cg.c:33
+    if (!d || !q || G < 3 || rows < 1 || row0 < 0 || row0 + rows > G)
+        return fail(CG_ERR_ARG, "cg_stencil_noalloc: need G >= 3 and 0 <= row0 < row0+rows <= G");
+    if ((row0 > 0 && !top) || (row0 + rows < G && !bot))
+        return fail(CG_ERR_ARG, "cg_stencil_noalloc: a block that does not touch the global boundary needs its halo row");
+    CGCHK(select_device(device));
+    if (device >= kMaxDevices) return fail(CG_ERR_ARG, "device index too large");
+    double *ptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_static_mu);
+        if (!g_static_ptr[device]) {                    // once per device, that device being current
+            void *p = nullptr;
+            HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_static_ptr[device] = static_cast<double *>(p);
+        }
+        ptr = g_static_ptr[device];
+    }
+    const bool al = aligned16(d) && aligned16(q) && (!top || aligned16(top)) && (!bot || aligned16(bot));
+    const TileGeom t = tile_geom(G, rows, al, 0);
+    if (t.ntiles > kStaticPartials)
+        return fail(CG_ERR_ARG, "cg_stencil_noalloc: %ld tiles exceed the %ld the static scratch array holds "
+                    "(blocks up to about %ld points fit); use cg_stencil", t.ntiles, kStaticPartials,
+                    kStaticPartials * 512L * 16L);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    StencilArgs a;
+    memset(&a, 0, sizeof a);
+    a.d_in = d; a.d_top = row0 > 0 ? top : nullptr; a.d_bot = row0 + rows < G ? bot : nullptr;
+    a.q = q; a.partials = ptr; a.sc = nullptr;
+    a.coef = coef_from9(poisson9);
+    a.G = G; a.rows = rows; a.row0 = row0; a.nstrips = t.nstrips; a.tile_h = t.tile_h; a.remap = 1;
+    launch_stencil<0, true>(t, a, s);                   // every tile of this call writes its slot: nothing to clear
+    HIPCHK(hipGetLastError());
+    if (dq_dev) {
+        hipLaunchKernelGGL(cg::k_sum_to, dim3(1), dim3(kBlock), 0, s, ptr, t.ntiles, dq_dev);
+        HIPCHK(hipGetLastError());
+    }
+    return CG_OK;
+}
+
 // ---------------------------------------------------------------- context ---
 
 int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks)
@@ -902,6 +1101,12 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(CG_ERR_ARG, "cg_create: bad rank %d of %d", rank, nranks);
     if (nranks == 1 && (row0 != 0 || rows != G))
         return fail(CG_ERR_ARG, "cg_create: a single rank must own the whole grid");
+    // Equal row blocks in rank order: the all-gathers of the dot products place rank r's partial sums at
+    // r * (its own count) and RCCL needs the same count on every rank.
+    if (nranks > 1 && (G % nranks != 0 || rows != G / nranks || row0 != (long)rank * rows))
+        return fail(CG_ERR_ARG, "cg_create: rank %d of %d must own rows [%ld, %ld) of the %ld-row grid "
+                    "(equal blocks in rank order; the grid side must be divisible by the rank count, cf. cg.c:23-26)",
+                    rank, nranks, (long)rank * (G / nranks), (long)(rank + 1) * (G / nranks), G);
     CGCHK(select_device(device));
 
     cg_ctx *c = new cg_ctx;
@@ -985,9 +1190,11 @@ int cg_destroy(cg_ctx *c)
 int cg_set_option(cg_ctx *c, int key, long value)
 {
     if (!c) return fail(CG_ERR_ARG, "cg_set_option: ctx is NULL");
+    CGCHK(materialise(c));                              // the next solve may run another schedule: start it from plain vectors
     switch (key) {
     case CG_OPT_REDUCE:
         if (value != CG_REDUCE_FAST && value != CG_REDUCE_STRICT) return fail(CG_ERR_ARG, "unknown reduction order %ld", value);
+        if (c->reduce != (int)value) c->live = false;   // q0 on the device was summed in the other order
         c->reduce = (int)value; break;
     case CG_OPT_SCHEDULE:
         if (value < -1 || value > CG_SCHED_LEAN) return fail(CG_ERR_ARG, "unknown schedule %ld", value);
@@ -1014,7 +1221,12 @@ int cg_set_option(cg_ctx *c, int key, long value)
     case CG_OPT_STRICT_BLOCKS:
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
             return fail(CG_ERR_ARG, "rank-grid side must be 0/1 (off), 2, 4 or 8");
+        if (c->strict_blocks != value) c->live = false;
         c->strict_blocks = value; break;
+    case CG_OPT_OVERLAP: c->overlap = value ? 1 : 0; break;
+    case CG_OPT_COMM_REHEARSAL:
+        if (value && c->nranks != 1) return fail(CG_ERR_ARG, "the communication rehearsal is for single-rank contexts");
+        c->rehearse = value ? 1 : 0; break;
     case CG_OPT_STRICT_IMPL:
         if (value < kStrictAuto || value > kStrictParallel) return fail(CG_ERR_ARG, "strict implementation must be 1, 2 or 3");
         c->strict_impl = (int)value; break;
@@ -1027,6 +1239,7 @@ int cg_set_option(cg_ctx *c, int key, long value)
 int cg_set_stencil(cg_ctx *c, const int *stencil9)
 {
     if (!c || !stencil9) return fail(CG_ERR_ARG, "cg_set_stencil: NULL argument");
+    CGCHK(materialise(c));
     c->coef = coef_from9(stencil9);
     drop_graph(c);                                      // captured launches hold the old coefficients
     return CG_OK;
@@ -1047,6 +1260,8 @@ int cg_get_option(cg_ctx *c, int key, long *value)
     case CG_OPT_STRICT_IMPL: *value = c->strict_impl; break;
     case CG_OPT_STRICT_BLOCKS: *value = c->strict_blocks; break;
     case CG_OPT_TILE_WGS: *value = ctx_geom(c).max_wgs; break;
+    case CG_OPT_OVERLAP: *value = c->overlap; break;
+    case CG_OPT_COMM_REHEARSAL: *value = c->rehearse; break;
     default: return fail(CG_ERR_ARG, "unknown option key %d", key);
     }
     return CG_OK;
@@ -1063,6 +1278,8 @@ int cg_init_problem(cg_ctx *c)
     c->set_gcur(0);
     c->lean_pending = 0;
     c->pending_dupdate = false;
+    c->live = false;
+    c->needs_init = false;
     c->q_valid = true;
     HIPCHK(hipMemsetAsync(c->u, 0, bytes, s));           // calloc, cg.c:44
     HIPCHK(hipMemsetAsync(c->q, 0, bytes, s));           // calloc, cg.c:45
@@ -1079,12 +1296,22 @@ int cg_init_problem(cg_ctx *c)
     return CG_OK;
 }
 
+int cg_sync_vectors(cg_ctx *c)
+{
+    if (!c) return fail(CG_ERR_ARG, "cg_sync_vectors: ctx is NULL");
+    return materialise(c);
+}
+
 int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
 {
     if (!c || !out) return fail(CG_ERR_ARG, "cg_solve: NULL argument");
     if (max_iters < 0 || rtol < 0) return fail(CG_ERR_ARG, "cg_solve: max_iters and rtol must be >= 0");
+    if (c->needs_init) return fail(CG_ERR_STATE, "cg_time_kernel overwrote the vectors: call cg_init_problem before solving");
     CGCHK(select_device(c->device));
     if (c->nranks > 1 && !c->comm) return fail(CG_ERR_STATE, "multi-rank context without cg_comm_init");
+    if (c->rehearse && (!c->comm || !c->comm->stream_ordered()))
+        return fail(CG_ERR_STATE, "CG_OPT_COMM_REHEARSAL needs cg_comm_init (RCCL) on the single-rank context");
+    if (c->rehearse) CGCHK(comm_rc(c, c->comm->prepare_rehearsal(c->G)));
     if (c->effective_schedule() == CG_SCHED_LEAN) CGCHK(lean_setup(c));   // may fall back to FUSED_NOQ (auto schedule only)
     const int sched = c->effective_schedule();
     hipStream_t s = c->stream;
@@ -1110,34 +1337,62 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         HIPCHK(c->xs.reserve(c->count));
         if (c->xs.cap_chunks != before) drop_graph(c);      // captured nodes hold the old workspace
     }
-    // history buffer (set-up, outside the timed region); at most 2^24 entries are kept
-    const long hist_want = max_iters < (1L << 24) ? max_iters : (1L << 24);
+    // History buffer (set-up, outside the timed region): room for at least 65536 iterations, so that
+    // solves of ordinary length never reallocate it (captured graphs hold its address); at most 2^24.
+    long hist_want = max_iters > (1L << 16) ? max_iters : (1L << 16);
+    if (hist_want > (1L << 24)) hist_want = 1L << 24;
     if (c->hist_cap < hist_want) {
-        drop_graph(c);                                  // the graph's k_finish nodes hold the old pointer
+        drop_graph(c);
         (void)hipFree(c->hist); c->hist = nullptr; c->hist_cap = 0;
         HIPCHK(hipMalloc(&c->hist, (size_t)hist_want * sizeof(double)));
         c->hist_cap = hist_want;
     }
-    // graph of the steady-state iteration body (set-up, outside the timed region)
+
+    // A solve that follows another one on the same state continues it: q0 is the q1 already on the device,
+    // and the d / u updates the last iteration left owed ride on this solve's first iteration, as between
+    // any two iterations.  Otherwise q0 = g.g is summed and the first iteration starts from a materialised d.
+    const bool cont = c->live;
+    const bool first_form = (sched == CG_SCHED_CLASSIC) ? false : !c->pending_dupdate;   // iteration 0 has no d update to fold in
+    const long lead = (first_form && max_iters > 0) ? 1 : 0;                             // iterations enqueued before the graph
+
+    // Graph of the steady-state iteration body (set-up, outside the timed region), for the buffer roles
+    // the context will be in after the leading iteration (which works in place and leaves no u update owed).
     long glen = c->graph_iters;
-    // Multi-rank: RCCL calls can be captured, but a capture that fails on some rank would
-    // take the whole job down, so a graph is used there only when asked for explicitly;
-    // the host-staged transport synchronises the stream and cannot be captured at all.
-    if (c->nranks > 1 && (!c->graph_explicit || !c->comm->stream_ordered())) glen = 0;
-    if (glen > 0 && max_iters - 1 >= glen) {
-        if (!c->graph || c->graph_sched != sched || c->graph_reduce != c->reduce || c->graph_dcur != c->dcur ||
-            (sched == CG_SCHED_LEAN && c->graph_gcur != c->gcur))
-            CGCHK(build_graph(c, glen));
-    } else {
-        glen = 0;
+    // The host-staged transport synchronises the stream and cannot be captured.  RCCL calls can: every rank
+    // captures, then all ranks agree (one all-gather of a flag) that every capture succeeded, else all run eagerly.
+    if (c->multi() && !c->comm->stream_ordered()) glen = 0;
+    GraphSlot *graph = nullptr;
+    if (glen > 0 && max_iters - lead >= glen) {
+        graph = find_graph(c, sched);
+        bool agree = c->multi() && graph == nullptr;
+        if (!graph) {
+            const int rc = build_graph(c, glen, &graph);
+            if (rc != CG_OK && !c->multi()) return rc;
+            if (rc != CG_OK) graph = nullptr;
+        }
+        if (agree && c->nranks > 1 && !c->comm->self_only()) {
+            const double mine = graph ? 1.0 : 0.0;
+            std::vector<double> all((size_t)c->nranks, 0.0);
+            HIPCHK(hipMemcpyAsync(c->comm->gather_buf() + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+            HIPCHK(hipMemcpyAsync(all.data(), c->comm->gather_buf(), all.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            bool ok = true;
+            for (double v : all) ok = ok && v == 1.0;
+            if (!ok) { drop_graph(c); graph = nullptr; c->graph_iters = 0; }      // every rank takes the same decision
+        }
     }
-    if (glen > 0 && c->graph) glen = c->graph_len;
-    if (glen == 0) drop_graph(c);
+    glen = graph ? graph->len : 0;
     HIPCHK(hipStreamSynchronize(s));
 
     const auto t0 = std::chrono::steady_clock::now();
-    // q0 = g.g (cg.c:55)
-    {
+    if (cont) {
+        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, (const double *)nullptr, 0L, (const double *)nullptr, 1,
+                           c->sc, 5, rtol, c->hist, c->hist_cap);
+        HIPCHK(hipGetLastError());
+    } else {
+        // q0 = g.g (cg.c:55)
         const TileGeom t = ctx_geom(c);
         const int fb = flat_blocks(c->count / t.vec, c->flat_blocks_opt);
         double *p0;
@@ -1149,16 +1404,15 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         }
         CGCHK(enqueue_dot_finish(c, c->g, c->g, p0, fb, 2, rtol));
     }
-    const int dcur_start = c->dcur, gcur_start = c->gcur;
-    c->lean_pending = 0;
+    const int dcur_start = c->dcur, gcur_start = c->gcur, pend_start = c->lean_pending;
     long launched = 0;
     bool stopped = false;
-    // Iteration 0 runs eagerly: the fused schedules have no d update to fold in yet.
-    if (max_iters > 0) { CGCHK(enqueue_iteration(c, true)); launched = 1; }
+    if (lead) { CGCHK(enqueue_iteration(c, true)); launched = 1; }
     while (launched < max_iters && !stopped) {
-        if (glen > 0 && max_iters - launched >= glen) {
-            HIPCHK(hipGraphLaunch(c->graph, s));
-            launched += glen;
+        if (glen > 0 && max_iters - launched >= glen && graph->dcur == c->dcur && graph->gcur == c->gcur &&
+            graph->pend == c->lean_pending) {
+            HIPCHK(hipGraphLaunch(graph->exec, s));
+            launched += glen;                           // an even number of iterations: the roles are as before
         } else {
             CGCHK(enqueue_iteration(c, false));
             launched += 1;
@@ -1177,30 +1431,31 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     const auto t1 = std::chrono::steady_clock::now();
 
     const Scalars &h = *c->host_sc;
-    // Fused schedules flip d's buffers once per executed iteration after the first;
-    // iterations skipped because the stop rule fired did not flip anything.
-    if (sched == CG_SCHED_LEAN) {
-        // Iteration 0 worked in place; each later one moved to the next direction buffer and
-        // the other gradient buffer.  Iterations skipped behind a fired stop rule moved nothing.
-        const long executed = (long)h.iter, moved = executed >= 1 ? executed - 1 : 0;
+    const long executed = (long)(h.iter - h.iter_base);   // iterations of this solve that really ran
+    // Buffer roles after `executed` iterations (those skipped behind a fired stop rule moved nothing): the
+    // leading iteration works in place, every other fused / lean iteration flips d (lean: and g).
+    if (sched != CG_SCHED_CLASSIC) {
+        const long moved = executed - (lead && executed >= 1 ? 1 : 0);
         c->dcur = dcur_start ^ (int)(moved & 1);
-        c->set_gcur(gcur_start ^ (int)(moved & 1));
-        CGCHK(enqueue_uflush(c, (int)(executed - (long)h.u_applied), c->dcur));   // u updates still outstanding
-        c->lean_pending = 0;
-        c->pending_dupdate = executed >= 1;
-        CGCHK(flush_pending_dupdate(c));
-        HIPCHK(hipStreamSynchronize(s));
-        c->q_valid = false;
-    } else if (sched != CG_SCHED_CLASSIC) {
-        const long executed = (long)h.iter;
-        c->dcur = (executed >= 1) ? (dcur_start ^ (int)((executed - 1) & 1)) : dcur_start;
-        c->pending_dupdate = executed >= 1;
-        CGCHK(flush_pending_dupdate(c));
-        HIPCHK(hipStreamSynchronize(s));
-        c->q_valid = (sched == CG_SCHED_FUSED);
+        if (sched == CG_SCHED_LEAN) {
+            c->set_gcur(gcur_start ^ (int)(moved & 1));
+            c->lean_pending = (int)(h.iter - h.u_applied);
+            c->q_valid = false;
+        } else {
+            c->set_gcur(gcur_start);
+            c->lean_pending = 0;
+            c->q_valid = (sched == CG_SCHED_FUSED);
+        }
+        if (executed >= 1) c->pending_dupdate = true;
+        (void)pend_start;
+    } else {
+        c->dcur = dcur_start;
+        c->set_gcur(gcur_start);
     }
-    c->hist_len = (long)h.iter < c->hist_cap ? (long)h.iter : c->hist_cap;
-    out->iters = (long)h.iter;
+    if (c->lean_pending < 0 || c->lean_pending > 1) return fail(CG_ERR_STATE, "lean schedule: %d u updates owed", c->lean_pending);
+    c->live = true;
+    c->hist_len = executed < c->hist_cap ? executed : c->hist_cap;
+    out->iters = executed;
     out->q1 = h.q1;
     out->q_init = h.q_init;
     out->seconds = std::chrono::duration<double>(t1 - t0).count();
@@ -1211,6 +1466,7 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
 int cg_device_ptr(cg_ctx *c, int which, double **out)
 {
     if (!c || !out) return fail(CG_ERR_ARG, "cg_device_ptr: NULL argument");
+    CGCHK(materialise(c));
     switch (which) {
     case CG_VEC_U: *out = c->u; break;
     case CG_VEC_G: *out = c->g; break;
@@ -1225,6 +1481,7 @@ int cg_copy_out(cg_ctx *c, int which, double *host_dst, long count)
 {
     if (!c || !host_dst) return fail(CG_ERR_ARG, "cg_copy_out: NULL argument");
     if (count != c->count) return fail(CG_ERR_ARG, "cg_copy_out: count %ld != block size %ld", count, c->count);
+    if (c->needs_init) return fail(CG_ERR_STATE, "cg_time_kernel overwrote the vectors: call cg_init_problem first");
     CGCHK(select_device(c->device));
     if (which == CG_VEC_Q && !c->q_valid)
         return fail(CG_ERR_STATE, "q is not stored by the LEAN and FUSED_NOQ schedules; use CLASSIC or FUSED to read it");
@@ -1257,6 +1514,12 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     // Give the prologue scalars harmless values: tau = 0 and beta = 1 keep the data bounded.
     if (sched == CG_SCHED_LEAN) CGCHK(lean_setup(c));
     if (c->effective_schedule() != sched) return fail(CG_ERR_HIP, "lean schedule: not enough free HBM");
+    if (t.ntiles > c->npart || tq.ntiles > c->npart)
+        return fail(CG_ERR_ARG, "%ld tiles exceed the %ld partial sums the context holds: use a larger CG_OPT_TILE_H",
+                    t.ntiles > tq.ntiles ? t.ntiles : tq.ntiles, c->npart);
+    // From here on the vectors and the device scalars are scratch: nothing owed, nothing to continue, and
+    // no solve or read-back until cg_init_problem has set the problem up again.
+    c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->needs_init = true;
     Scalars hs;
     memset(&hs, 0, sizeof hs);
     hs.q0 = 1.0; hs.tau = 0.0; hs.beta = 1.0;
@@ -1352,6 +1615,21 @@ int cg_comm_init(cg_ctx *c, const void *id128)
     c->comm = nullptr;
     char msg[256];
     cg::Comm *comm = cg::RcclComm::create(id128, c->rank, c->nranks, c->has_top(), c->has_bot(), msg, sizeof msg);
+    if (!comm) return fail(CG_ERR_COMM, "%s", msg);
+    c->comm = comm;
+    drop_graph(c);
+    return CG_OK;
+}
+
+int cg_comm_init_self(cg_ctx *c)
+{
+    if (!c) return fail(CG_ERR_ARG, "cg_comm_init_self: NULL context");
+    CGCHK(select_device(c->device));
+    delete c->comm;
+    c->comm = nullptr;
+    char msg[256], id[128];
+    if (cg::RcclComm::unique_id(id, msg, sizeof msg) != 0) return fail(CG_ERR_COMM, "%s", msg);
+    cg::Comm *comm = cg::RcclComm::create(id, c->rank, c->nranks, c->has_top(), c->has_bot(), msg, sizeof msg, true);
     if (!comm) return fail(CG_ERR_COMM, "%s", msg);
     c->comm = comm;
     drop_graph(c);

@@ -19,6 +19,8 @@ OPT_STRICT_IMPL = 8
 OPT_TILE_WGS = 9
 OPT_PREFETCH_READ = 11
 OPT_STRICT_BLOCKS = 12
+OPT_OVERLAP = 13
+OPT_COMM_REHEARSAL = 14
 STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL = 1, 2, 3
 VEC_U, VEC_G, VEC_D, VEC_Q = 0, 1, 2, 3
 
@@ -56,6 +58,9 @@ SIGNATURES = {
     "cg_stencil9": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p, _dp]),
     "cg_dot": (C.c_int, [C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_double, _dp]),
+    "cg_verify_u": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_double, _dp, _dp]),
+    "cg_stencil_noalloc": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_axpy": (C.c_int, [C.c_int, C.c_long, C.c_double, C.c_void_p, C.c_void_p]),
     "cg_xpay": (C.c_int, [C.c_int, C.c_long, C.c_double, C.c_void_p, C.c_void_p]),
     "cg_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int]),
@@ -65,12 +70,14 @@ SIGNATURES = {
     "cg_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long)]),
     "cg_init_problem": (C.c_int, [C.c_void_p]),
     "cg_solve": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.POINTER(Result)]),
+    "cg_sync_vectors": (C.c_int, [C.c_void_p]),
     "cg_copy_out": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
     "cg_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "cg_get_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long)]),
     "cg_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp]),
     "cg_comm_unique_id": (C.c_int, [C.c_void_p]),
     "cg_comm_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cg_comm_init_self": (C.c_int, [C.c_void_p]),
     "cg_comm_init_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_comm_selftest": (C.c_int, [C.c_void_p]),
 }

@@ -75,9 +75,12 @@ def init_g(count, d, g, device=0):
     _l.check(_l.load().cg_init_g(device, count, _p(d), _p(g)))
 
 
-def _stencil9(coef5):
-    """(up, left, centre, right, down) -> the 3x3 row-wise integer array of a stencil_struct (cg.c:33)."""
-    up, left, centre, right, down = (int(x) for x in coef5)
+def _stencil9(coef):
+    """(up, left, centre, right, down), or all nine entries row-wise -> the 3x3 integer array of a stencil_struct (cg.c:33)."""
+    c = [int(x) for x in coef]
+    if len(c) == 9:
+        return (C.c_int * 9)(*c)
+    up, left, centre, right, down = c
     return (C.c_int * 9)(0, up, 0, left, centre, right, 0, down, 0)
 
 
@@ -91,6 +94,18 @@ def stencil(G, row0, rows, d, q, top=None, bot=None, device=0, want_dq=False, co
         _l.check(_l.load().cg_stencil9(device, _stencil9(coef5), G, row0, rows, _p(d), _p(top), _p(bot), _p(q),
                                        C.byref(dq) if want_dq else None))
     return dq.value if want_dq else None
+
+
+def stencil_noalloc(G, row0, rows, d, q, top=None, bot=None, device=0, dq=None, stream=None):
+    """cg_stencil without any allocation: enqueued on `stream` (None = the null stream), d.q to the device vector `dq`."""
+    _l.check(_l.load().cg_stencil_noalloc(device, G, row0, rows, _p(d), _p(top), _p(bot), _p(q), _p(dq), stream))
+
+
+def verify_u(n, row0, rows, u, sum_start=0.0, device=0):
+    """(sequential sum of the block of u continued from sum_start, max |u - x(1-x)y(1-y)|), both formed on the device."""
+    s, e = C.c_double(0.0), C.c_double(0.0)
+    _l.check(_l.load().cg_verify_u(device, n, row0, rows, _p(u), float(sum_start), C.byref(s), C.byref(e)))
+    return s.value, e.value
 
 
 def dot(count, v, w, strict=False, start=0.0, device=0):
@@ -127,14 +142,15 @@ class CGSolver:
         ctx = C.c_void_p()
         _l.check(self._lib.cg_create(C.byref(ctx), self.device, self.n, self.row0, self.rows, self.rank, self.nranks))
         self._ctx = ctx
-        self.reduce, self.schedule = _l.REDUCE_FAST, None          # None = the library picks (LEAN, FUSED when strict)
+        self.reduce, self.schedule = _l.REDUCE_FAST, None          # None = the library picks (LEAN; FUSED_NOQ if HBM is short)
 
     # -- configuration ---------------------------------------------------
     def set_option(self, key, value):
         _l.check(self._lib.cg_set_option(self._ctx, key, int(value)))
 
     def configure(self, reduce=None, schedule=None, tile_h=None, graph_iters=None, xcd_remap=None,
-                  flat_blocks=None, prefetch=None, strict_impl=None, tile_wgs=None, prefetch_read=None, strict_blocks=None):
+                  flat_blocks=None, prefetch=None, strict_impl=None, tile_wgs=None, prefetch_read=None, strict_blocks=None,
+                  overlap=None, comm_rehearsal=None):
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
@@ -159,11 +175,15 @@ class CGSolver:
             self.set_option(_l.OPT_STRICT_BLOCKS, strict_blocks)
         if prefetch_read is not None:
             self.set_option(_l.OPT_PREFETCH_READ, prefetch_read)
+        if overlap is not None:
+            self.set_option(_l.OPT_OVERLAP, 1 if overlap else 0)
+        if comm_rehearsal is not None:
+            self.set_option(_l.OPT_COMM_REHEARSAL, 1 if comm_rehearsal else 0)
         return self
 
-    def set_stencil(self, coef5):
-        """Coefficients (up, left, centre, right, down): entries 1, 3, 4, 5, 7 of the reference's array."""
-        _l.check(self._lib.cg_set_stencil(self._ctx, _stencil9(coef5)))
+    def set_stencil(self, coef):
+        """Five coefficients (up, left, centre, right, down: entries 1, 3, 4, 5, 7 of the reference's array) or all nine."""
+        _l.check(self._lib.cg_set_stencil(self._ctx, _stencil9(coef)))
         return self
 
     def get_option(self, key):
@@ -192,6 +212,10 @@ class CGSolver:
         buf = C.create_string_buffer(bytes(id128), 128)
         _l.check(self._lib.cg_comm_init(self._ctx, buf))
 
+    def comm_init_self(self):
+        """One-rank RCCL communicator standing in for every peer of a multi-rank context (timing rehearsal on one GPU)."""
+        _l.check(self._lib.cg_comm_init_self(self._ctx))
+
     def comm_init_host(self, transport):
         """Carry halo rows and dot-product partials over `transport` (dist.RowTransport) instead of RCCL.
 
@@ -219,6 +243,17 @@ class CGSolver:
         r = _l.Result()
         _l.check(self._lib.cg_solve(self._ctx, int(max_iters), float(rtol), C.byref(r)))
         return SolveResult(r.iters, r.q1, r.q_init, r.seconds, bool(r.converged))
+
+    def sync_vectors(self):
+        """Apply the u / d updates the last solve left owed (collective over the ranks)."""
+        _l.check(self._lib.cg_sync_vectors(self._ctx))
+        return self
+
+    def verify(self, sum_start=0.0):
+        """(sequential sum of this block's u continued from sum_start, max |u - exact|) on the device."""
+        p = C.c_void_p()
+        _l.check(self._lib.cg_device_ptr(self._ctx, _l.VEC_U, C.byref(p)))
+        return verify_u(self.n, self.row0, self.rows, p, sum_start, self.device)
 
     def vector(self, which):
         out = np.empty(self.count, dtype=np.float64)

@@ -65,8 +65,12 @@ int cg_init_g(int device, long count, const double *d, double *g);
 int cg_stencil(int device, long G, long row0, long rows, const double *d,
                const double *top, const double *bot, double *q, double *dq_host);
 /* The same with the coefficients of a stencil_struct (utils.h:3-7): stencil9 is the 3x3 integer
- * array, row-wise (host pointer).  As in the reference only entries 1, 3, 4, 5, 7 -- up, left,
- * centre, right, down -- are read (utils.c:27-31); cg_stencil uses cg.c:33's {0,-1,0,-1,4,-1,0,-1,0}. */
+ * array, row-wise (host pointer); cg_stencil uses cg.c:33's {0,-1,0,-1,4,-1,0,-1,0}.  The reference's
+ * kernels read entries 1, 3, 4, 5, 7 -- up, left, centre, right, down -- only (utils.c:27-31) although
+ * the struct and its unused corner_pad (utils.h:15) are laid out for all nine.  Here all nine are
+ * honoured: with non-zero corner entries the sum of utils.c:25-31 is continued over the whole array in
+ * array order (row above left to right, own row, row below); with zero corners the five-term code runs
+ * and the result is the reference's bit for bit. */
 int cg_stencil9(int device, const int *stencil9, long G, long row0, long rows, const double *d,
                 const double *top, const double *bot, double *q, double *dq_host);
 /* *result_host = sum v[k]*w[k], k = 0..count-1.  strict != 0: one accumulator in
@@ -81,10 +85,33 @@ int cg_stencil9(int device, const int *stencil9, long G, long row0, long rows, c
  * Replaces the local part of dot, utils.c:368-379.                           */
 int cg_dot(int device, long count, const double *v, const double *w, int strict,
            double start, double *result_host);
+/* Checks of a solution block u (global rows [row0, row0+rows) of the (n+1)^2 grid) on the device -- the
+ * reference's only inspection hook is the array dump print_local2dmesh (utils.c:352-366), whose one call
+ * site is commented out (cg.c:135):
+ *   *sum_u_host   = sum_start + u[0] + u[1] + ... added one by one in index order (the order of
+ *                   utils.c:372-379); ranks owning consecutive row blocks pass the value on as
+ *                   sum_start, which gives the single-rank bits;
+ *   *max_err_host = max |u - x(1-x) y(1-y)| over the block, x = i/n, y = j/n: the distance to the
+ *                   closed-form solution of the problem init_locald sets up (utils.c:334).
+ * Either output pointer may be NULL.                                         */
+int cg_verify_u(int device, long n, long row0, long rows, const double *u, double sum_start,
+                double *sum_u_host, double *max_err_host);
 /* y[k] += a*x[k].  Replaces the loops at cg.c:63-76.                         */
 int cg_axpy(int device, long count, double a, const double *x, double *y);
 /* d[k] = b*d[k] - g[k].  Replaces the loop at cg.c:81-87.                    */
 int cg_xpay(int device, long count, double b, double *d, const double *g);
+
+/* cg_stencil for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The same kernels, with
+ * their scratch -- one partial sum per tile -- in a fixed device array of 512 KiB that every GPU the
+ * library runs on holds until the process ends, instead of library-allocated memory.  It allocates
+ * nothing, creates no stream and does not synchronise: the work is enqueued on `stream` (a hipStream_t;
+ * NULL = the null stream) and is complete when that stream reaches it.  dq_dev (DEVICE pointer, may be
+ * NULL) receives d.q in the fast order, the value cg_stencil returns through dq_host.  Blocks that need
+ * more than 65536 tiles (about 5e8 points) are rejected with CG_ERR_ARG.  All calls on one GPU share
+ * the array: calls that overlap in time on the same GPU race on it.           */
+int cg_stencil_noalloc(int device, long G, long row0, long rows, const double *d, const double *top,
+                       const double *bot, double *q, double *dq_dev, void *stream);
 
 /* ---- whole-solve context -------------------------------------------------
  * Replaces the body of main between set-up and output (cg.c:41-134).         */
@@ -122,6 +149,11 @@ typedef struct cg_ctx cg_ctx;
                                   utils.c:408-417), the s*s sums combined as MPICH's MPI_Allreduce combines
                                   them (utils.c:380) -- and so reproduces the bits of `mpirun -np s*s ./cg`.
                                   0 or 1 = the single-rank order (default) */
+#define CG_OPT_OVERLAP     13  /* several ranks, lean schedule: 1 (default) = the new gradient's boundary rows travel on a
+                                  second stream while the rows between them are computed; 0 = exchange in line */
+#define CG_OPT_COMM_REHEARSAL 14 /* single-rank context with cg_comm_init: 1 = issue the per-iteration traffic of a
+                                  multi-rank solve anyway (a grouped send/receive of two rows to the rank itself, the
+                                  two all-gathers of the partial sums), to put a number on its cost with one GPU */
 #define CG_OPT_TILE_WGS    9   /* cap on workgroups per tiled launch; with more tiles than that each
                                   workgroup walks several tiles in turn.  0 = auto (256 with automatic
                                   tile height, one workgroup per tile with an explicit CG_OPT_TILE_H) */
@@ -131,11 +163,11 @@ typedef struct cg_ctx cg_ctx;
 int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks);
 int cg_destroy(cg_ctx *ctx);
 int cg_set_option(cg_ctx *ctx, int key, long value);
-/* Coefficients of the context's stencil: the 3x3 integer array of a stencil_struct (cg.c:33-38),
- * of which entries 1, 3, 4, 5, 7 are used, as in utils.c:27-31.  Default: cg.c:33's values. */
+/* Coefficients of the context's stencil: the 3x3 integer array of a stencil_struct (cg.c:33-38), all nine
+ * entries (see cg_stencil9; the reference reads entries 1, 3, 4, 5, 7 only).  Default: cg.c:33's values. */
 int cg_set_stencil(cg_ctx *ctx, const int *stencil9);
-/* Current value of an option; for CG_OPT_SCHEDULE, CG_OPT_TILE_H, CG_OPT_TILE_WGS and
- * CG_OPT_U_DEFER the value in effect after automatic selection. */
+/* Current value of an option; for CG_OPT_SCHEDULE, CG_OPT_TILE_H and CG_OPT_TILE_WGS the value in
+ * effect after automatic selection. */
 int cg_get_option(cg_ctx *ctx, int key, long *value);
 
 /* u = 0, q = 0, d = d0, g = -d0 (cg.c:41-45 via utils.c:276-350).            */
@@ -154,8 +186,21 @@ typedef struct cg_result {
 /* Run at most max_iters iterations from the context's current state (call
  * cg_init_problem first).  rtol > 0 adds the stop rule q1 <= rtol^2 * q_init,
  * evaluated on the device after every iteration; the vectors are left exactly
- * as they were when it fired.  rtol = 0 is the reference's fixed count.      */
+ * as they were when it fired.  rtol = 0 is the reference's fixed count.
+ * A solve that follows another one on the same context continues it: q0 is the
+ * q1 the last iteration left on the device (the same g.g, cg.c:55 and :89), so
+ * K1 + K2 iterations in two calls give the bits of K1 + K2 in one.
+ * The fused and lean schedules fold `d = beta*d - g` (cg.c:81-87) into the next
+ * iteration's kernels, the lean one also every other `u += tau*d` (cg.c:63-69);
+ * when a solve returns, the last of these updates may still be owed.  They are
+ * applied by the next cg_solve (as part of its first iteration) or by whatever
+ * looks at the vectors first: cg_copy_out, cg_device_ptr, cg_sync_vectors,
+ * cg_set_option, cg_set_stencil.  With several ranks that step exchanges halo
+ * rows, so those calls are collective there: make them on every rank.        */
 int cg_solve(cg_ctx *ctx, long max_iters, double rtol, cg_result *out);
+/* Apply the updates the last solve left owed (see cg_solve): afterwards u, g and d hold
+ * what the reference's loop holds after the same iterations.                 */
+int cg_sync_vectors(cg_ctx *ctx);
 
 #define CG_VEC_U 0
 #define CG_VEC_G 1
@@ -163,7 +208,7 @@ int cg_solve(cg_ctx *ctx, long max_iters, double rtol, cg_result *out);
 #define CG_VEC_Q 3
 /* Copy one of the context's vectors (rows*(n+1) doubles) to host memory.     */
 int cg_copy_out(cg_ctx *ctx, int which, double *host_dst, long count);
-/* Device pointer of one of the context's vectors (valid until cg_destroy or
+/* Device pointer of one of the context's vectors, for reading (valid until cg_destroy or
  * the next cg_solve, which may move d and g to their other buffers).         */
 int cg_device_ptr(cg_ctx *ctx, int which, double **out);
 /* q1 of every iteration of the last solve (host pointer, up to `count`; the first 2^24
@@ -177,13 +222,15 @@ int cg_get_history(cg_ctx *ctx, double *host_dst, long count, long *written);
  *        1 = update kernel, 2 = d-update kernel (CLASSIC only).
  * Outputs the mean milliseconds per launch and the algorithmic bytes one
  * launch moves (the per-point figure of the schedule times the block's points).
- * The vectors are modified; re-initialise before solving again.              */
+ * The vectors are overwritten: cg_solve and cg_copy_out fail with CG_ERR_STATE until
+ * cg_init_problem has been called again.                                     */
 int cg_time_kernel(cg_ctx *ctx, int which, int reps, double *ms_per_launch, double *bytes_per_launch);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------
  * Replaces init_mpi_settings (utils.c:383-420), exchange_boundaries
  * (utils.c:221-274, rows only) and the MPI_Allreduce in dot (utils.c:380).
- * Rank r owns rows [r*G/P, (r+1)*G/P).  The 128-byte id comes from rank 0's
+ * Rank r owns rows [r*G/P, (r+1)*G/P): equal blocks in rank order, P must divide G = n+1
+ * (cg_create rejects anything else).  The 128-byte id comes from rank 0's
  * cg_comm_unique_id and reaches the other ranks through any host channel
  * (torch.distributed / MPI broadcast).                                       */
 int cg_comm_unique_id(void *id128);
@@ -205,6 +252,13 @@ typedef int (*cg_exchange_fn)(void *user, const double *send_up, const double *s
                               double *recv_top, double *recv_bot, long count);
 typedef int (*cg_allgather_fn)(void *user, const double *mine, long count, double *all);
 int cg_comm_init_host(cg_ctx *ctx, cg_exchange_fn exchange, cg_allgather_fn allgather, void *user);
+
+/* Timing rehearsal on one GPU: the context keeps its place in a P-rank decomposition (its row block, its halo
+ * rows, its slice of the all-gather buffers), but a ONE-rank RCCL communicator stands in for every peer -- rows
+ * are sent to and received from the calling rank itself, the all-gathers cover its own slice.  The numbers such
+ * a solve produces mean nothing; what it shows is the time one rank's iteration takes with the RCCL calls of the
+ * real schedule in it.  (No counterpart in the reference.) */
+int cg_comm_init_self(cg_ctx *ctx);
 
 /* Transport self-test, collective over the ranks of the communicator: an all-gather of one
  * tagged double per rank, a tagged row exchange with the neighbours above and below, and one

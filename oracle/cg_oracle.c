@@ -43,10 +43,25 @@ void oracle_init_g(long count, const double *d, double *g)
 /* Entries 1, 3, 4, 5, 7 of the reference's 3x3 integer coefficient array (cg.c:33: up, left,
  * centre, right, down); the other four are never read by its kernels (utils.c:27-31). */
 static int coef_up = -1, coef_left = -1, coef_centre = 4, coef_right = -1, coef_down = -1;
+/* Entries 0, 2, 6, 8 (the corners).  The reference declares them (utils.h:3-7, cg.c:33) but no
+ * kernel of it reads them, so NO reference output pins the corner terms: with non-zero corners
+ * this restatement defines the operator (the loop of utils.c:25-31 continued over all nine
+ * entries in array order) and parity for those terms is UNPINNED.  With zero corners the
+ * five-term code below runs, untouched. */
+static int coef_ul = 0, coef_ur = 0, coef_dl = 0, coef_dr = 0;
 
 void oracle_set_stencil(const int c5[5])
 {
     coef_up = c5[0]; coef_left = c5[1]; coef_centre = c5[2]; coef_right = c5[3]; coef_down = c5[4];
+    coef_ul = coef_ur = coef_dl = coef_dr = 0;
+}
+
+/* All nine entries of the 3x3 array, row-wise as cg.c:33 lists them. */
+void oracle_set_stencil9(const int c9[9])
+{
+    coef_ul = c9[0]; coef_up = c9[1]; coef_ur = c9[2];
+    coef_left = c9[3]; coef_centre = c9[4]; coef_right = c9[5];
+    coef_dl = c9[6]; coef_down = c9[7]; coef_dr = c9[8];
 }
 
 /* One stencil point; the five terms are added to a zero-initialised
@@ -64,11 +79,29 @@ static inline double stencil_point(double up, double left, double centre,
     return acc;
 }
 
+/* The nine-entry continuation of the same loop: array order 0..8, i.e. row above left to
+ * right, own row, row below (no counterpart in the reference's kernels; see above). */
+static inline double stencil_point9(const double *up, const double *cur, const double *down, long j)
+{
+    double acc = 0;
+    acc += (double)coef_ul * up[j - 1];
+    acc += (double)coef_up * up[j];
+    acc += (double)coef_ur * up[j + 1];
+    acc += (double)coef_left * cur[j - 1];
+    acc += (double)coef_centre * cur[j];
+    acc += (double)coef_right * cur[j + 1];
+    acc += (double)coef_dl * down[j - 1];
+    acc += (double)coef_down * down[j];
+    acc += (double)coef_dr * down[j + 1];
+    return acc;
+}
+
 /* utils.c:15-35 for rows whose neighbours are inside the block, utils.c:74-104
  * for the first/last row of a block that has a halo row. */
 void oracle_stencil(long G, long row0, long rows, const double *d,
                     const double *top, const double *bot, double *q)
 {
+    const int corners = coef_ul != 0 || coef_ur != 0 || coef_dl != 0 || coef_dr != 0;
     for (long r = 0; r < rows; ++r) {
         const long gi = row0 + r;
         if (gi == 0 || gi == G - 1) continue;          /* Dirichlet rows: untouched */
@@ -76,8 +109,11 @@ void oracle_stencil(long G, long row0, long rows, const double *d,
         const double *up = (r > 0) ? cur - G : top;
         const double *down = (r < rows - 1) ? cur + G : bot;
         double *out = q + r * G;
-        for (long j = 1; j < G - 1; ++j)
-            out[j] = stencil_point(up[j], cur[j - 1], cur[j], cur[j + 1], down[j]);
+        if (corners)
+            for (long j = 1; j < G - 1; ++j) out[j] = stencil_point9(up, cur, down, j);
+        else
+            for (long j = 1; j < G - 1; ++j)
+                out[j] = stencil_point(up[j], cur[j - 1], cur[j], cur[j + 1], down[j]);
     }
 }
 

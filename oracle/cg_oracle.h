@@ -89,5 +89,10 @@ long oracle_cg_blocks2d(long n, long s, long max_iters, double rtol,
 /* Coefficients used by every stencil evaluation from now on: up, left, centre, right, down
  * (entries 1, 3, 4, 5, 7 of cg.c:33's array).  Process-wide; default -1, -1, 4, -1, -1. */
 void oracle_set_stencil(const int c5[5]);
+/* All nine entries of the 3x3 array, row-wise (cg.c:33).  The reference's kernels never read
+ * entries 0, 2, 6, 8 (utils.c:27-31): with non-zero corners the operator is this file's own
+ * nine-term continuation of utils.c:25-31 in array order, and parity for the corner terms is
+ * UNPINNED (no reference output exists for them).  Zero corners: exactly oracle_set_stencil. */
+void oracle_set_stencil9(const int c9[9]);
 
 #endif

@@ -59,8 +59,15 @@ DEFAULT_STENCIL = (-1, -1, 4, -1, -1)
 
 
 def set_stencil(c5=DEFAULT_STENCIL):
-    """Coefficients (up, left, centre, right, down) of every later stencil evaluation; process-wide."""
-    load().oracle_set_stencil((C.c_int * 5)(*[int(x) for x in c5]))
+    """Coefficients of every later stencil evaluation; process-wide.
+
+    Five values: (up, left, centre, right, down), the entries the reference reads.  Nine values: the
+    whole 3x3 array row-wise; the corner terms have no counterpart in the reference (parity unpinned)."""
+    c = [int(x) for x in c5]
+    if len(c) == 9:
+        load().oracle_set_stencil9((C.c_int * 9)(*c))
+    else:
+        load().oracle_set_stencil((C.c_int * 5)(*c))
 
 
 def init_d(n, row0=0, rows=None):

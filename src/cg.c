@@ -19,10 +19,19 @@
  *   CG_STRICT_NP=P  with CG_STRICT=1 on one GPU: the summation layout of the reference run
  *                   on P = 4, 16 or 64 ranks, i.e. the bits of `mpirun -np P ./cg n`
  *   CG_SCHEDULE=classic|fused|fused_noq|lean   kernel schedule of the solve path
- *                   (default lean; fused in strict order, which needs q stored)
+ *                   (default lean; fused_noq when HBM is too short for lean's second gradient buffer)
  *   CG_STENCIL="up,left,centre,right,down"   other values for the five entries of cg.c:33's
- *                   coefficient array that the reference's kernels read (default -1,-1,4,-1,-1)
- *   CG_DUMP=prefix  write the final u as raw doubles to <prefix>.u.f64 (1 rank)
+ *                   coefficient array that the reference's kernels read (default -1,-1,4,-1,-1);
+ *                   nine values set the whole 3x3 array row-wise, corners included (the reference
+ *                   declares those entries but never reads them)
+ *   CG_DUMP=prefix  write the final u, g, d as raw doubles to <prefix>.{u,g,d}.f64: the whole grid in
+ *                   row-major order on any number of ranks (the ranks append their row blocks in turn).
+ *                   The reference's counterpart is the array dump whose call is commented out (cg.c:135).
+ *   CG_VERIFY=1     one more line "[VERIFY] sum_u = ... max_err = ...": the sum of u added one by one in
+ *                   index order (handed from rank to rank) and max |u - x(1-x)y(1-y)|, the distance to the
+ *                   closed-form solution of the problem; both formed on the GPUs
+ *   CG_TRANSPORT=host   several ranks, solve path: halo rows and partial sums staged through the host and
+ *                   carried by MPI instead of RCCL (ranks that share one GPU, or no RCCL)
  *
  * Output on rank 0: the reference's two lines (cg.c:139-140) followed by one
  * machine-readable line with full-precision q1, rates and achieved bandwidth.
@@ -64,6 +73,78 @@ static void barrier(void)
 #endif
 }
 
+#ifdef CG_USE_MPI
+/* Host-staged transport of the solve path (cg_comm_init_host): the two exchanges carried by MPI. */
+typedef struct { int rank, numprocs; } host_transport;
+
+static int mpi_exchange(void *user, const double *send_up, const double *send_down, double *recv_top,
+                        double *recv_bot, long count)
+{
+    const host_transport *t = (const host_transport *)user;
+    MPI_Status st;
+    if (send_down != NULL)                 /* last row down, the lower neighbour's first row back (utils.c:234-239) */
+        MPI_Sendrecv(send_down, (int)count, MPI_DOUBLE, t->rank + 1, 11, recv_bot, (int)count, MPI_DOUBLE,
+                     t->rank + 1, 12, MPI_COMM_WORLD, &st);
+    if (send_up != NULL)                   /* first row up, the upper neighbour's last row back (utils.c:243-248) */
+        MPI_Sendrecv(send_up, (int)count, MPI_DOUBLE, t->rank - 1, 12, recv_top, (int)count, MPI_DOUBLE,
+                     t->rank - 1, 11, MPI_COMM_WORLD, &st);
+    return 0;
+}
+
+static int mpi_allgather(void *user, const double *mine, long count, double *all)
+{
+    (void)user;
+    /* `mine` is this rank's slice of `all`: gather in place */
+    (void)mine;
+    return MPI_Allgather(MPI_IN_PLACE, (int)count, MPI_DOUBLE, all, (int)count, MPI_DOUBLE, MPI_COMM_WORLD) == MPI_SUCCESS ? 0 : 1;
+}
+#endif
+
+/* CG_VERIFY and CG_DUMP on the final vectors (device pointers of this rank's row block). */
+static void inspect(int device, int rank, int numprocs, int n, long row0, long rows, const double *u,
+                    const double *g, const double *d)
+{
+    const long G = (long)n + 1, count = rows * G;
+    const char *ver = getenv("CG_VERIFY");
+    if (ver && *ver && *ver != '0') {
+        double start = 0.0, sum_u = 0.0, max_err = 0.0;
+#ifdef CG_USE_MPI
+        MPI_Status st;
+        if (rank > 0) MPI_Recv(&start, 1, MPI_DOUBLE, rank - 1, 78, MPI_COMM_WORLD, &st);
+#endif
+        CK(cg_verify_u(device, n, row0, rows, u, start, &sum_u, &max_err), "cg_verify_u");
+#ifdef CG_USE_MPI
+        if (rank < numprocs - 1) MPI_Send(&sum_u, 1, MPI_DOUBLE, rank + 1, 78, MPI_COMM_WORLD);
+        MPI_Bcast(&sum_u, 1, MPI_DOUBLE, numprocs - 1, MPI_COMM_WORLD);
+        double all_max = max_err;
+        MPI_Allreduce(&max_err, &all_max, 1, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD);
+        max_err = all_max;
+#endif
+        if (rank == 0) printf("[VERIFY] sum_u = %.17e (%a) max_err = %.6e\n", sum_u, sum_u, max_err);
+    }
+    const char *dump = getenv("CG_DUMP");
+    if (dump && *dump) {
+        const double *vec[3] = {u, g, d};
+        const char *ext[3] = {"u", "g", "d"};
+        double *h = (double *)malloc((size_t)count * sizeof(double));
+        if (!h) { fprintf(stderr, "[ERROR] out of host memory\n"); exit(1); }
+        for (int v = 0; v < 3; ++v) {
+            if (vec[v] == NULL) continue;
+            char fn[4096];
+            snprintf(fn, sizeof fn, "%s.%s.f64", dump, ext[v]);
+            for (int r = 0; r < numprocs; ++r) {       /* row blocks in rank order = the grid in row-major order */
+                if (r == rank) {
+                    CK(cg_copy_to_host(device, h, vec[v], count), "cg_copy_to_host");
+                    FILE *f = fopen(fn, r == 0 ? "wb" : "ab");
+                    if (f) { fwrite(h, sizeof(double), (size_t)count, f); fclose(f); }
+                }
+                barrier();
+            }
+        }
+        free(h);
+    }
+}
+
 int main(int argc, char **argv)
 {
     int rank = 0, numprocs = 1;
@@ -97,18 +178,21 @@ int main(int argc, char **argv)
     int my_stencil[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};              /* cg.c:33 */
     const char *ste = getenv("CG_STENCIL");
     if (ste && *ste) {
-        int v[5];
-        if (sscanf(ste, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5) {
-            if (rank == 0) printf("[ERROR] CG_STENCIL needs five integers: up,left,centre,right,down.\n");
+        int v[9];
+        const int got = sscanf(ste, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]);
+        if (got == 9) {
+            memcpy(my_stencil, v, sizeof my_stencil);
+        } else if (got == 5) {
+            my_stencil[1] = v[0]; my_stencil[3] = v[1]; my_stencil[4] = v[2]; my_stencil[5] = v[3]; my_stencil[7] = v[4];
+        } else {
+            if (rank == 0) printf("[ERROR] CG_STENCIL needs five integers (up,left,centre,right,down) or all nine.\n");
             return 1;
         }
-        my_stencil[1] = v[0]; my_stencil[3] = v[1]; my_stencil[4] = v[2]; my_stencil[5] = v[3]; my_stencil[7] = v[4];
     }
 
     double q1 = 0.0, q_init = 0.0, runtime = 0.0;
     long done_iters = 0;
     int bytes_per_point = 88;
-    double *u_dev = NULL;
     int device = 0;
 
     if (use_calls) {
@@ -152,17 +236,7 @@ int main(int argc, char **argv)
         }
         barrier();                                                     /* cg.c:131 */
         runtime = now_s() - t0;
-        u_dev = localu;
-        const char *dump = getenv("CG_DUMP");
-        if (dump && *dump && numprocs == 1) {
-            double *h = (double *)malloc((size_t)count * sizeof(double));
-            char fn[4096];
-            snprintf(fn, sizeof fn, "%s.u.f64", dump);
-            CK(cg_copy_to_host(device, h, u_dev, count), "cg_copy_to_host");
-            FILE *f = fopen(fn, "wb");
-            if (f) { fwrite(h, sizeof(double), (size_t)count, f); fclose(f); }
-            free(h);
-        }
+        inspect(device, rank, numprocs, n, row0, rows, localu, localg, locald);
         cg_free(device, localu); cg_free(device, localg); cg_free(device, localq);
         free_struct_elems(stencil, ld, settings);
         free(ld); free(stencil); free(settings);
@@ -190,11 +264,17 @@ int main(int argc, char **argv)
             CK(cg_set_option(ctx, CG_OPT_STRICT_BLOCKS, side), "cg_set_option(strict blocks)");
         }
 #ifdef CG_USE_MPI
+        host_transport ht = {rank, numprocs};
         if (numprocs > 1) {
-            char id[128];
-            if (rank == 0) CK(cg_comm_unique_id(id), "cg_comm_unique_id");
-            MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
-            CK(cg_comm_init(ctx, id), "cg_comm_init");
+            const char *tr = getenv("CG_TRANSPORT");
+            if (tr && strcmp(tr, "host") == 0) {
+                CK(cg_comm_init_host(ctx, mpi_exchange, mpi_allgather, &ht), "cg_comm_init_host");
+            } else {
+                char id[128];
+                if (rank == 0) CK(cg_comm_unique_id(id), "cg_comm_unique_id");
+                MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+                CK(cg_comm_init(ctx, id), "cg_comm_init");
+            }
         }
 #endif
         CK(cg_init_problem(ctx), "cg_init_problem");
@@ -202,21 +282,17 @@ int main(int argc, char **argv)
         barrier();
         const double t0 = now_s();
         CK(cg_solve(ctx, iters, rtol, &res), "cg_solve");
+        CK(cg_sync_vectors(ctx), "cg_sync_vectors");                   /* the reference's timed region ends with u, g, d final */
         barrier();
         runtime = now_s() - t0;
         q1 = res.q1; q_init = res.q_init; done_iters = res.iters;
         CK(cg_get_option(ctx, CG_OPT_SCHEDULE, &sched), "cg_get_option(schedule)");   /* the one that ran */
         bytes_per_point = sched == CG_SCHED_CLASSIC ? 88 : sched == CG_SCHED_FUSED ? 80 : sched == CG_SCHED_FUSED_NOQ ? 64 : 56;
-        const char *dump = getenv("CG_DUMP");
-        if (dump && *dump && numprocs == 1) {
-            double *h = (double *)malloc((size_t)count * sizeof(double));
-            char fn[4096];
-            snprintf(fn, sizeof fn, "%s.u.f64", dump);
-            CK(cg_copy_out(ctx, CG_VEC_U, h, count), "cg_copy_out");
-            FILE *f = fopen(fn, "wb");
-            if (f) { fwrite(h, sizeof(double), (size_t)count, f); fclose(f); }
-            free(h);
-        }
+        double *u_dev = NULL, *g_dev = NULL, *d_dev = NULL;
+        CK(cg_device_ptr(ctx, CG_VEC_U, &u_dev), "cg_device_ptr(u)");
+        CK(cg_device_ptr(ctx, CG_VEC_G, &g_dev), "cg_device_ptr(g)");
+        CK(cg_device_ptr(ctx, CG_VEC_D, &d_dev), "cg_device_ptr(d)");
+        inspect(device, rank, numprocs, n, row0, rows, u_dev, g_dev, d_dev);
         cg_destroy(ctx);
     }
 

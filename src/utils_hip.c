@@ -41,7 +41,7 @@ static int cur_device(void) { return g_settings ? g_settings->device : 0; }
 static void check_stencil(const stencil_struct *s)
 {
     /* The reference's kernels are written for the 3x3 array (utils.c:27-31 index it directly);
-     * its five cross entries are passed on as they are. */
+     * all nine entries are passed on as they are (the reference itself reads the five cross entries only). */
     if (s == NULL || s->size != 3 || s->extent != 1 || s->stencil == NULL) {
         fprintf(stderr, "[ERROR] only the 3x3 stencil of extent 1 is supported\n");
         exit(1);

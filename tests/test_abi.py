@@ -44,6 +44,29 @@ def test_compat_header_symbols_exported_by_driver_object():
         assert re.search(r"\b%s\s*\(" % n, src), n
 
 
+def test_reference_driver_compiles_against_the_dropin_header():
+    # The reference's own cg.c (its call sites cg.c:30-146 of the nine utils.h entry points, its struct
+    # member accesses) must compile unchanged against include/utils.h.
+    ref = "/root/reference/cg.c"
+    mpi_inc = "/opt/conda/include"
+    if not (os.path.exists(ref) and os.path.exists(os.path.join(mpi_inc, "mpi.h"))):
+        pytest.skip("reference sources or an MPI header are not present on this machine")
+    import subprocess
+    p = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", mpi_inc,
+                        "-include", "mpi.h", ref], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+
+
+def test_unequal_row_blocks_are_rejected(cg):
+    # the all-gathers of the partial sums need the same count on every rank: equal blocks in rank order
+    lib = cg.lib.load()
+    ctx = ctypes.c_void_p()
+    assert lib.cg_create(ctypes.byref(ctx), 0, 20, 0, 10, 0, 2) != 0       # 21 rows over 2 ranks
+    assert b"equal blocks" in lib.cg_last_error()
+    assert lib.cg_create(ctypes.byref(ctx), 0, 19, 5, 10, 0, 2) != 0       # right size, wrong place
+    assert b"equal blocks" in lib.cg_last_error()
+
+
 def test_no_gpu_means_loud_failure(cg):
     # On a machine without a GPU every compute entry point must fail, never fall back.
     if cg.device_count() > 0:

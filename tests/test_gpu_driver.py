@@ -52,8 +52,54 @@ def test_calls_path_strict_is_bit_identical_and_dumps_u(golden, tmp_path):
     prefix = str(tmp_path / "dump")
     _, m = run(["63", "50"], env={"CG_PATH": "calls", "CG_STRICT": "1", "CG_DUMP": prefix})
     assert m.group(2) == rec["q1_hex"]
-    u = np.fromfile(prefix + ".u.f64", dtype="<f8").reshape(64, 64)
-    assert np.array_equal(bits(u), bits(golden_arrays(rec["arrays"], 63)["u"]))
+    want = golden_arrays(rec["arrays"], 63)
+    for k in ("u", "g", "d"):
+        got = np.fromfile(prefix + f".{k}.f64", dtype="<f8").reshape(64, 64)
+        assert np.array_equal(bits(got), bits(want[k])), k
+
+
+VERIFY = re.compile(r"\[VERIFY\] sum_u = (\S+) \((\S+)\) max_err = (\S+)")
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+@pytest.mark.parametrize("n,iters", [(255, 200), (1023, 200)])
+@pytest.mark.parametrize("ranks,path", [(1, "solve"), (1, "calls"), (4, "solve"), (4, "calls")])
+def test_verifier_and_dump_on_one_and_four_ranks(golden, tmp_path, n, iters, ranks, path):
+    # CG_VERIFY: sum(u) in index order (handed from rank to rank) and max |u - exact|, formed on the GPU, against
+    # the numbers the reference run printed for the goldens; CG_DUMP: the whole grid, rank blocks appended in turn.
+    rec = golden[(n, iters, 1, 0.0)]
+    prefix = str(tmp_path / "dump")
+    env = {"CG_STRICT": "1", "CG_VERIFY": "1", "CG_DUMP": prefix, "CG_PATH": path, "CG_TRANSPORT": "host"}
+    lines, m = run([str(n), str(iters)], env=env, mpi=ranks if ranks > 1 else 0)
+    assert m.group(2) == rec["q1_hex"]
+    v = VERIFY.search("\n".join(lines))
+    assert v, lines
+    assert v.group(2) == rec["sum_u_hex"]
+    assert abs(float(v.group(3)) - float(rec["max_err"])) <= 2e-6 * float(rec["max_err"])
+    G = n + 1
+    u = np.fromfile(prefix + ".u.f64", dtype="<f8")
+    assert u.size == G * G
+    x = np.arange(G) / n
+    assert abs(np.max(np.abs(u.reshape(G, G) - np.outer(x * (1 - x), x * (1 - x)))) - float(rec["max_err"])) <= 2e-6 * float(rec["max_err"])
+    for k in ("g", "d"):
+        assert np.fromfile(prefix + f".{k}.f64", dtype="<f8").size == G * G
+    if "arrays" in rec:
+        want = golden_arrays(rec["arrays"], n)
+        for k in ("u", "g", "d"):
+            assert np.array_equal(bits(np.fromfile(prefix + f".{k}.f64", dtype="<f8").reshape(G, G)), bits(want[k])), k
+
+
+@pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")
+def test_driver_nine_entry_stencil(oracle):
+    import sys
+    coef = (-1, -1, -1, -1, 8, -1, -1, -1, -1)
+    oracle.set_stencil(coef)
+    try:
+        ref = oracle.cg(63, 40)
+    finally:
+        oracle.set_stencil()
+    _, m = run(["63", "40"], env={"CG_STRICT": "1", "CG_STENCIL": ",".join(str(c) for c in coef)})
+    assert m.group(2) == float(ref["q1"]).hex()
 
 
 @pytest.mark.skipif(not os.path.exists(CG), reason="C driver not built")

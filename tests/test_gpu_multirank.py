@@ -11,10 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("schedule", ["classic", "fused", "fused_noq", "lean"])
-@pytest.mark.parametrize("world,n,iters", [(2, 255, 60), (4, 255, 60), (4, 1023, 120), (2, 20, 12), (3, 20, 12), (7, 20, 12)])
+@pytest.mark.parametrize("world,n,iters", [(2, 255, 60), (4, 255, 60), (4, 1023, 120), (3, 20, 12), (7, 20, 12)])
 def test_multirank_matches_single_rank(oracle, tmp_path, schedule, world, n, iters):
-    if (n + 1) % world:
-        pytest.skip("grid side not divisible")
     res = run_ranks(world, ["gpu", n, iters, tmp_path, schedule], tmp_path)
     ref = oracle.cg(n, iters)
     assert all(int(r["iters"]) == iters for r in res)
@@ -80,3 +78,32 @@ def test_rccl_calls_on_a_single_rank_communicator(cg):
     r = s.init_problem().solve(20)                # the solve itself ignores a one-rank communicator
     ref = cg.CGSolver(255).init_problem().solve(20)
     assert float(r.q1).hex() == float(ref.q1).hex()
+
+
+@pytest.mark.parametrize("graph", [0, 10])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_calls_inside_the_iteration_on_one_rank(cg, graph, overlap):
+    # CG_OPT_COMM_REHEARSAL: a single-rank solve that issues the per-iteration RCCL traffic of a multi-rank one
+    # (grouped send/receive of two rows to itself, the all-gathers of the partial sums) -- eagerly and captured in
+    # a hipGraph, in line and on the second stream.  The traffic must not change a bit of the result.
+    ref = cg.CGSolver(1023).configure(graph_iters=graph).init_problem()
+    r0 = ref.solve(45)
+    s = cg.CGSolver(1023)
+    s.comm_init(cg.CGSolver.comm_unique_id())
+    s.configure(graph_iters=graph, overlap=overlap, comm_rehearsal=True).init_problem()
+    r = s.solve(45)
+    assert r.iters == 45
+    if not overlap:                                # same tiles, same order of partial sums
+        assert float(r.q1).hex() == float(r0.q1).hex()
+        assert np.array_equal(s.vector(cg.VEC_U).view(np.uint64), ref.vector(cg.VEC_U).view(np.uint64))
+    else:                                          # the edge rows form tiles of their own: another (fixed) order
+        assert abs(r.q1 - r0.q1) <= 1e-9 * r0.q1
+        assert np.allclose(s.vector(cg.VEC_U), ref.vector(cg.VEC_U), rtol=1e-9, atol=1e-15)
+
+
+def test_self_addressed_communicator_runs_a_block_of_a_larger_decomposition(cg):
+    # timing rehearsal path (tools/rccl_rehearsal.py): rank 1 of 4 with a one-rank RCCL communicator for all peers
+    s = cg.CGSolver(1023, row0=256, rows=256, rank=1, nranks=4)
+    s.comm_init_self()
+    r = s.configure(graph_iters=10).init_problem().solve(33)
+    assert r.iters == 33 and r.seconds > 0

@@ -281,6 +281,44 @@ def test_solve_can_be_continued(cg, sched, split):
     assert abs(ra.q1 - rb.q1) <= 1e-9 * rb.q1
     assert np.allclose(a.vector(cg.VEC_U), b.vector(cg.VEC_U), rtol=1e-9, atol=1e-15)
     assert np.allclose(a.vector(cg.VEC_D), b.vector(cg.VEC_D), rtol=1e-6, atol=1e-13)
+    # a solve that follows another continues from the q1 on the device: two calls give the bits of one
+    one = cg.CGSolver(255).configure(schedule=sid).init_problem()
+    r1 = one.solve(37)
+    assert float(ra.q1).hex() == float(r1.q1).hex()
+    for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+        assert np.array_equal(bits(a.vector(which)), bits(one.vector(which))), which
+
+
+@pytest.mark.parametrize("order", ["fast", "strict"])
+def test_many_short_solves_equal_one_long_solve_bitwise(cg, order):
+    # every parity of direction buffer, gradient buffer and deferred u update at the seams; reading the vectors
+    # in between (which applies the owed updates) must not disturb the continuation either
+    red = cg.REDUCE_STRICT if order == "strict" else cg.REDUCE_FAST
+    one = cg.CGSolver(255).configure(reduce=red).init_problem()
+    one.solve(61)
+    many = cg.CGSolver(255).configure(reduce=red).init_problem()
+    hist = []
+    for k, look in ((1, False), (2, False), (3, True), (10, False), (11, False), (4, True), (1, True), (1, False), (28, False)):
+        r = many.solve(k)
+        hist.append(many.history(k))
+        if look:
+            many.vector(cg.VEC_U)
+    assert float(r.q1).hex() == float(one.history(61)[-1]).hex()
+    assert np.array_equal(bits(np.concatenate(hist)), bits(one.history(61)))
+    for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+        assert np.array_equal(bits(many.vector(which)), bits(one.vector(which))), which
+
+
+def test_time_kernel_leaves_the_context_unusable_until_reinitialised(cg):
+    s = cg.CGSolver(255).init_problem()
+    s.solve(5)
+    s.time_kernel(0, reps=2)
+    with pytest.raises(cg.CGError):
+        s.solve(5)
+    with pytest.raises(cg.CGError):
+        s.vector(cg.VEC_U)
+    r = s.init_problem().solve(20)
+    assert float(r.q1).hex() == float(cg.CGSolver(255).init_problem().solve(20).q1).hex()
 
 
 # ----------------------------------------------------- full-size properties --
@@ -409,6 +447,91 @@ def test_standalone_stencil_with_coefficients_bitwise(cg, oracle):
     d, q = cg.DeviceVector.from_host(d_h), cg.DeviceVector(G * G)
     cg.stencil(G, 0, G, d, q, coef5=coef)
     assert np.array_equal(bits(q.to_host().reshape(G, G)), bits(want))
+
+
+# ------------------------------------------------ nine-point stencil (corner entries) -------
+# The reference's stencil_struct has nine entries (utils.h:3-7, cg.c:33) but its kernels read five
+# (utils.c:27-31): no reference output exists for non-zero corners.  These tests pin the kernels
+# against the CPU restatement's nine-term sum (array order 0..8); parity for the corner terms is
+# UNPINNED against the reference itself.
+
+NINE = (1, -2, 3, -4, 20, -5, 2, -3, 1)
+
+
+@pytest.mark.parametrize("G", [3, 4, 21, 257, 512, 514, 1500])
+def test_nine_point_stencil_bitwise_against_the_restatement(cg, oracle, rng, G):
+    d_h = rng.standard_normal((G, G))
+    q0 = rng.standard_normal((G, G))
+    oracle.set_stencil(NINE)
+    try:
+        want = oracle.stencil(d_h, q=q0.copy())
+    finally:
+        oracle.set_stencil()
+    d, q = cg.DeviceVector.from_host(d_h), cg.DeviceVector.from_host(q0)
+    cg.stencil(G, 0, G, d, q, coef5=NINE)
+    assert np.array_equal(bits(q.to_host().reshape(G, G)), bits(want))
+
+
+@pytest.mark.parametrize("G,row0,rows", [(64, 16, 16), (257, 100, 57), (1024, 512, 256), (21, 20, 1), (1024, 1, 1)])
+def test_nine_point_row_block_with_halos_bitwise(cg, oracle, rng, G, row0, rows):
+    full = rng.standard_normal((G, G))
+    oracle.set_stencil(NINE)
+    try:
+        want = oracle.stencil(full)[row0:row0 + rows]
+    finally:
+        oracle.set_stencil()
+    d = cg.DeviceVector.from_host(np.ascontiguousarray(full[row0:row0 + rows]))
+    q = cg.DeviceVector(rows * G)
+    t = cg.DeviceVector.from_host(np.ascontiguousarray(full[row0 - 1])) if row0 > 0 else None
+    b = cg.DeviceVector.from_host(np.ascontiguousarray(full[row0 + rows])) if row0 + rows < G else None
+    cg.stencil(G, row0, rows, d, q, top=t, bot=b, coef5=NINE)
+    assert np.array_equal(bits(q.to_host()), bits(want.ravel()))
+
+
+@pytest.mark.parametrize("sched", ["classic", "fused", "fused_noq", "lean"])
+@pytest.mark.parametrize("n,iters", [(63, 30), (255, 61)])
+def test_nine_point_strict_solve_bitwise_against_the_restatement(cg, oracle, sched, n, iters):
+    coef = (-1, -1, -1, -1, 8, -1, -1, -1, -1)          # the usual nine-point Laplacian: symmetric positive definite
+    oracle.set_stencil(coef)
+    try:
+        ref = oracle.cg(n, iters)
+    finally:
+        oracle.set_stencil()
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, schedule=getattr(cg, SCHEDS[sched])).set_stencil(coef)
+    r = s.init_problem().solve(iters)
+    assert np.array_equal(bits(s.history(iters)), bits(ref["hist"]))
+    assert float(r.q1).hex() == float(ref["q1"]).hex()
+    for k, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+        assert np.array_equal(bits(s.vector(which)), bits(ref[k])), k
+
+
+def test_nine_entries_with_zero_corners_are_the_five_point_results(cg, golden):
+    rec = golden[(63, 50, 1, 0.0)]
+    s = cg.CGSolver(63).configure(reduce=cg.REDUCE_STRICT).set_stencil((0, -1, 0, -1, 4, -1, 0, -1, 0))
+    r = s.init_problem().solve(50)
+    assert float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex()
+    want = golden_arrays(rec["arrays"], 63)
+    for k, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+        assert np.array_equal(bits(s.vector(which)), bits(want[k])), k
+
+
+# -------------------------------------------------------- solution checks on the device -----
+
+@pytest.mark.parametrize("n,iters", [(15, 10), (255, 200), (1023, 200)])
+def test_device_side_sum_and_error_match_the_reference(cg, golden, n, iters):
+    # sum(u) in index order and max |u - exact|: the two numbers the reference run printed for the goldens
+    rec = golden[(n, iters, 1, 0.0)]
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT).init_problem()
+    s.solve(iters)
+    sum_u, max_err = s.verify()
+    assert float(sum_u).hex() == rec["sum_u_hex"]
+    assert abs(max_err - float(rec["max_err"])) <= 1e-6 * float(rec["max_err"])
+    # handed on in two pieces, as two ranks would
+    G = n + 1
+    u = cg.DeviceVector.from_host(s.vector(cg.VEC_U))
+    first, e1 = cg.verify_u(n, 0, G // 2, u)
+    both, e2 = cg.verify_u(n, G // 2, G - G // 2, u.offset((G // 2) * G), sum_start=first)
+    assert float(both).hex() == rec["sum_u_hex"] and max(e1, e2) == max_err
 
 
 # ------------------------------------------------------------ smallest grids -----

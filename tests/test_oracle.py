@@ -144,3 +144,35 @@ def test_oracle_with_other_stencil_coefficients_matches_reference(oracle, golden
             assert np.array_equal(bits(res[k]), bits(want[k])), k
     if "sum_u_hex" in rec:
         assert float(seq_sum(oracle, res["u"])).hex() == rec["sum_u_hex"]
+
+
+def test_nine_point_restatement_self_consistency(oracle):
+    # The corner terms have no counterpart in the reference (utils.c:27-31 reads five entries): parity for them is
+    # unpinned.  What can be pinned on the CPU: zero corners give the five-term bits, and the nine-term sum is the
+    # loop of utils.c:25-31 continued in array order.
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((37, 37))
+    five = oracle.stencil(d)
+    oracle.set_stencil((0, -1, 0, -1, 4, -1, 0, -1, 0))
+    try:
+        nine0 = oracle.stencil(d)
+    finally:
+        oracle.set_stencil()
+    assert np.array_equal(five.view(np.int64), nine0.view(np.int64))
+    c = (1, -2, 3, -4, 20, -5, 2, -3, 1)
+    oracle.set_stencil(c)
+    try:
+        got = oracle.stencil(d)
+    finally:
+        oracle.set_stencil()
+    want = np.zeros_like(d)
+    for i in range(1, 36):
+        for j in range(1, 36):
+            acc = 0.0
+            k = 0
+            for di in (-1, 0, 1):
+                for dj in (-1, 0, 1):
+                    acc += float(c[k]) * d[i + di, j + dj]
+                    k += 1
+            want[i, j] = acc
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))

@@ -52,13 +52,19 @@ open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 # machine-readable traffic of the two hot kernels, keyed the way bench.py names them
 import json, re
 cfg = {}
-m = re.search(r'"grid": (\d+).*?"schedule": "(\w+)"', open(os.path.join(src, "trace.log")).read())
+log = open(os.path.join(src, "trace.log")).read()
+m = re.search(r'"grid": (\d+).*?"schedule": "(\w+)"', log)
 if m:
     cfg = {"grid": int(m.group(1)), "schedule": m.group(2)}
+m = re.search(r'"reduce": "(\w+)"', log)
+cfg["reduce"] = m.group(1) if m else "fast"
+m = re.search(r'"source_id": "(\w+)"', log)          # identity of the kernel sources the profile was taken on
+if m:
+    cfg["source_id"] = m.group(1)
 role = {"1": "stencil", "0": "stencil", "2": "update", "3": "pass1_dq", "4": "pass2_g", "5": "pass2_g_u"}
 kern = {}
 for k in dur:
-    mm = re.match(r"void cg::k_stencil<\d+, (\d), \w+, \d+(?:, \w+)?>", k)
+    mm = re.match(r"void cg::k_stencil<\d+, (\d), ", k)
     name = role.get(mm.group(1)) if mm else ("update" if "k_update" in k else "dupdate" if "k_dupdate" in k else None)
     if name is None or not fetch.get(k) or not write.get(k) or len(dur[k]) < 10:
         continue

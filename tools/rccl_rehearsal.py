@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""What the RCCL calls of a multi-rank iteration cost, measured with the one GPU at hand.
+
+  python tools/rccl_rehearsal.py [n] [nranks] [iters]
+
+One rank's row block of an n+1 grid split over `nranks` (an interior block: halo rows on both sides) runs the
+real lean schedule three ways: (a) kernels only (cg_time_kernel sums), (b) with the iteration's RCCL calls
+addressed to the rank itself (cg_comm_init_self: one grouped send/receive of two rows, two all-gathers of the
+partial sums), launched eagerly, (c) the same captured in a hipGraph.  The solve's numbers mean nothing here
+(the peers are missing); the per-iteration times do.
+"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+cg = importlib.import_module("conjugate-gradient_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16383
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+G = n + 1
+rows = G // P
+print(f"block {rows} x {G} (rank 1 of {P})", flush=True)
+s = cg.CGSolver(n, row0=rows, rows=rows, rank=1, nranks=P)
+k = [s.time_kernel(w, reps=50)[0] for w in (0, 1, 2)]
+kern = k[0] + (k[1] + k[2]) / 2
+print(f"kernels only: pass1 {k[0]*1e3:.1f} us, pass2 {k[1]*1e3:.1f} us, pass2+u {k[2]*1e3:.1f} us -> {kern*1e3:.1f} us per iteration", flush=True)
+for label, graph, overlap in (("eager, exchange in line", 0, False), ("eager, exchange overlapped", 0, True),
+                              ("hipGraph of 10, exchange in line", 10, False), ("hipGraph of 10, exchange overlapped", 10, True)):
+    t = cg.CGSolver(n, row0=rows, rows=rows, rank=1, nranks=P)
+    t.comm_init_self()
+    t.configure(graph_iters=graph, overlap=overlap).init_problem()
+    t.solve(21)                                            # warm-up: RCCL's first calls, graph capture
+    r = t.solve(iters)
+    per = r.seconds / max(r.iters, 1)
+    print(f"{label:38s}: {per*1e6:8.1f} us per iteration  (+{(per - kern)*1e6:6.1f} us over the kernels, "
+          f"{100 * kern / per:5.1f} % of the time is kernels)", flush=True)
+    t.close()
