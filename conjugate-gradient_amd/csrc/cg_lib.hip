@@ -504,10 +504,11 @@ constexpr long kEdgeRows = 8;
 //   every second pass 2 also:               u = (u + tau_{i-1}*d_{i-1}) + tau_i*d_i  (both operands are at hand)
 // 16 + 32 + 16/2 = 56 B per point against 64 for the schedule that stores d' between the passes, and
 // pass 1 is a pure read stream.  Same arithmetic in the same order: bit-identical vectors.
-// Several ranks: pass 2 does the block's first and last kEdgeRows rows first; their g_{i+1} rows then go
-// to the neighbours on the communication stream while the other rows are computed (the reference's
-// post - interior - wait - edges of utils.c:45-104, with the edges first because it is their OUTPUT that
-// travels here); the stream joins before the iteration ends, so every iteration is self-contained.
+// Several ranks: pass 2 computes the block's first and last kEdgeRows rows in two small launches on the
+// communication stream, which then sends their g_{i+1} rows to the neighbours, all of it beside the large
+// launch for the rows in between on the main stream (the reference's post - interior - wait - edges of
+// utils.c:45-104, with the edges first because it is their OUTPUT that travels here); the streams join
+// before the dot product is completed, so every iteration is self-contained (capturable as it stands).
 int enqueue_lean_iteration(cg_ctx *c)
 {
     hipStream_t s = c->stream;
@@ -554,27 +555,31 @@ int enqueue_lean_iteration(cg_ctx *c)
     b.g_out = c->g_buf[c->gcur ^ 1];
     b.u = c->u;
     const bool with_u = c->lean_pending == 1;             // the previous iteration's u update is outstanding: do both
-    auto pass2 = [&](const TileGeom &tg, long lo, long hi, long base) -> long {
-        return with_u ? launch_stencil<5, false>(tg, b, s, lo, hi, base) : launch_stencil<4, false>(tg, b, s, lo, hi, base);
+    auto pass2 = [&](hipStream_t on, const TileGeom &tg, long lo, long hi, long base) -> long {
+        return with_u ? launch_stencil<5, false>(tg, b, on, lo, hi, base) : launch_stencil<4, false>(tg, b, on, lo, hi, base);
     };
     if (overlap) {
+        // Fork: the communication stream computes the edge rows (two small launches that run beside the large
+        // one) and sends their gradient rows off; the main stream computes the rows in between.  Join before
+        // the dot product is completed: it needs the edge tiles' partial sums, and by then the rows have landed.
         TileGeom te = t;                                   // one tile per strip at each end
         te.tile_h = (int)kEdgeRows;
-        pass2(te, 0, kEdgeRows, 0);
-        pass2(te, c->rows - kEdgeRows, c->rows, t.nstrips);
-        HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
+        pass2(c->comm_stream, te, 0, kEdgeRows, 0);
+        pass2(c->comm_stream, te, c->rows - kEdgeRows, c->rows, t.nstrips);
+        HIPCHK(hipGetLastError());
         CGCHK(exchange_g_rows(c, c->comm_stream, b.g_out));
         HIPCHK(hipEventRecord(c->ev_halo, c->comm_stream));
-        pass2(ti, kEdgeRows, c->rows - kEdgeRows, 2 * (long)t.nstrips);
+        pass2(s, ti, kEdgeRows, c->rows - kEdgeRows, 2 * (long)t.nstrips);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamWaitEvent(s, c->ev_halo, 0));
     } else {
-        pass2(t, 0, c->rows, 0);
+        pass2(s, t, 0, c->rows, 0);
+        HIPCHK(hipGetLastError());
         if (c->multi()) CGCHK(exchange_g_rows(c, s, b.g_out));
     }
-    HIPCHK(hipGetLastError());
     CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
-    if (overlap) HIPCHK(hipStreamWaitEvent(s, c->ev_halo, 0));         // join: the halo rows have landed
     c->dcur = out;
     c->set_gcur(c->gcur ^ 1);
     c->lean_pending = with_u ? 0 : 1;

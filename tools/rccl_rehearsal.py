@@ -29,7 +29,7 @@ for label, graph, overlap in (("eager, exchange in line", 0, False), ("eager, ex
     t.configure(graph_iters=graph, overlap=overlap).init_problem()
     t.solve(21)                                            # warm-up: RCCL's first calls, graph capture
     r = t.solve(iters)
-    per = r.seconds / max(r.iters, 1)
-    print(f"{label:38s}: {per*1e6:8.1f} us per iteration  (+{(per - kern)*1e6:6.1f} us over the kernels, "
+    per = 1e3 * r.seconds / max(r.iters, 1)               # ms, like the kernel times
+    print(f"{label:38s}: {per*1e3:8.1f} us per iteration  (+{(per - kern)*1e3:6.1f} us over the kernels, "
           f"{100 * kern / per:5.1f} % of the time is kernels)", flush=True)
     t.close()
