@@ -37,6 +37,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <climits>
+#include <initializer_list>
+#include <vector>
+
+#include "cg_kernels.hpp"
 
 namespace cg {
 namespace exact {
@@ -214,6 +218,105 @@ __device__ __forceinline__ void fetch_chunk(const double *__restrict__ v, const 
     }
 }
 
+// ---- where the products come from ---------------------------------------------------------------
+// The ordered walk (D) and the repair of chunks whose speculation missed need single products and whole
+// chunks of them.  Two sources: arrays (v*w, or v alone when it already holds the rounded products), and
+// the lean schedule's first pass, which stores nothing: there product k is d'[k] * (A d')[k] with
+// d' = beta*d - g, recomputed from d and g with the arithmetic of the tiled kernel (cg_kernels.hpp,
+// k_stencil MODE 3: rounded multiply, then subtract; the stencil sum in the reference's order; q = 0 off
+// the interior, so the product there is d' * 0).
+struct SrcArrays {
+    const double *v, *w;
+    long count;
+    int vec;                                            // both arrays 16-byte aligned
+    static constexpr int kLds = 2;                      // doubles of LDS a wavefront needs for chunk16 (none)
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ double product(long k) const { return (w != nullptr) ? v[k] * w[k] : v[k]; }
+    // The products of elements lo + 16*lane + i, i = 0..15 (zero from `hi` on).
+    __device__ __forceinline__ void chunk16(long lo, long hi, int lane, double *, double (&p)[kPerLane]) const
+    {
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const long idx = lo + (long)lane * kPerLane + i;
+            p[i] = (idx < hi) ? product(idx) : 0.0;
+        }
+    }
+};
+
+struct SrcStencil {
+    const double *d, *g;                                // row r of either at base + r*G, r = -1 .. rows (halo rows in place)
+    const Scalars *sc;
+    Coef9 coef;
+    long G, rows, row0, count;                          // G a multiple of kChunk: a chunk lies inside one row
+    double beta;
+    static constexpr int kRow = kChunk + 8;             // d' of one row segment with its two outer columns, padded
+    static constexpr int kLds = 3 * kRow;
+    __device__ __forceinline__ void prepare() { beta = sc->beta; }
+    __device__ __forceinline__ double dp(long k) const { return beta * d[k] - g[k]; }
+    __device__ __forceinline__ double product(long k) const
+    {
+        const long m = k / G, j = k - m * G, gi = row0 + m;
+        const double c = dp(k);
+        if (gi < 1 || gi > G - 2 || j < 1 || j > G - 2) return c * 0.0;
+        double q;
+        if (coef.nine)
+            q = nine_point(coef, dp(k - G - 1), dp(k - G), dp(k - G + 1), dp(k - 1), c, dp(k + 1), dp(k + G - 1), dp(k + G),
+                           dp(k + G + 1));
+        else
+            q = five_point(coef, dp(k - G), dp(k - 1), c, dp(k + 1), dp(k + G));
+        return c * q;
+    }
+    // The chunk that starts at element lo (a multiple of kChunk): the wavefront fetches the three rows of d and g
+    // it needs with coalesced 16-byte loads, all in flight together, forms d' into LDS (T: kLds doubles of this
+    // wavefront), and every lane then evaluates its 16 consecutive products from there.
+    __device__ __forceinline__ void chunk16(long lo, long hi, int lane, double *T, double (&p)[kPerLane]) const
+    {
+        const long m = lo / G, j0 = lo - m * G, gi = row0 + m;
+        xv2 dv[3][kChunk / 128], gv[3][kChunk / 128];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const long base = (m + rr - 1) * G + j0;
+#pragma unroll
+            for (int k = 0; k < kChunk / 128; ++k) {
+                dv[rr][k] = *reinterpret_cast<const xv2 *>(d + base + k * 128 + 2 * lane);
+                gv[rr][k] = *reinterpret_cast<const xv2 *>(g + base + k * 128 + 2 * lane);
+            }
+        }
+        double edge = 0.0;                              // lanes 0..2: column j0-1 of the three rows; lanes 3..5: column j0+kChunk
+        if (lane < 6) {
+            const int rr = lane % 3;
+            const long col = (lane < 3) ? j0 - 1 : j0 + kChunk;
+            if (col >= 0 && col < G) edge = dp((m + rr - 1) * G + col);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int k = 0; k < kChunk / 128; ++k) {
+                double *dst = T + rr * kRow + 1 + k * 128 + 2 * lane;
+                dst[0] = beta * dv[rr][k].x - gv[rr][k].x;
+                dst[1] = beta * dv[rr][k].y - gv[rr][k].y;
+            }
+        if (lane < 6) T[(lane % 3) * kRow + ((lane < 3) ? 0 : kChunk + 1)] = edge;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool row_in = (gi >= 1) && (gi <= G - 2);
+        const double *U = T + 1, *M = T + kRow + 1, *D = T + 2 * kRow + 1;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const int c = lane * kPerLane + i;
+            const long j = j0 + c;
+            const bool in = row_in && (j >= 1) && (j <= G - 2);
+            double q;
+            if (coef.nine) q = nine_point(coef, U[c - 1], U[c], U[c + 1], M[c - 1], M[c], M[c + 1], D[c - 1], D[c], D[c + 1]);
+            else q = five_point(coef, U[c], M[c - 1], M[c], M[c + 1], D[c]);
+            p[i] = (lo + c < hi) ? M[c] * (in ? q : 0.0) : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the buffer's next use
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 // ---- A: approximate chunk sums ------------------------------------------------
 // `vec` = both arrays are 16-byte aligned (chunk bases are even, so pairs are aligned too).
 __global__ __launch_bounds__(256) void k_xs_approx(const double *__restrict__ v, const double *__restrict__ w,
@@ -285,8 +388,9 @@ __global__ __launch_bounds__(256) void k_xs_gsum(double *__restrict__ approx, lo
 // In-place exclusive scan of the group sums, seeded with `start` (or, when `start_dev` is
 // given, with the device-resident value it points to).  One workgroup.
 __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, long ngroups, double start,
-                                                   const double *start_dev)
+                                                   const double *start_dev, int *zero_me = nullptr)
 {
+    if (zero_me != nullptr && threadIdx.x == 0) *zero_me = 0;      // the repair list of the speculative path starts empty
     if (start_dev != nullptr) start = *start_dev;
     __shared__ double wave_tot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -315,14 +419,33 @@ __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, lo
 // ---- B: per-chunk integer summaries under the guessed exponent --------------------
 // Persistent wavefronts: each walks its own run of chunks and keeps the NEXT chunk's products in
 // flight while it summarises the current one.
+// Summary of one chunk whose products `cur` a wavefront holds lane-interleaved (as fetch_chunk delivers them),
+// under hypothesis e: the lanes trade them through LDS (T: 64 x 18 doubles of this wavefront) for 16
+// CONSECUTIVE elements each; 18-double rows keep the 16-byte reads of the 16 lanes of a group on distinct banks.
+__device__ __forceinline__ Summary chunk_summary(const double (&cur)[kPerLane], int e, double *T, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < kPerLane / 2; ++k) {
+        const int pos = k * 128 + 2 * lane;
+        double *dst = T + (pos >> 4) * 18 + (pos & 15);
+        dst[0] = cur[2 * k]; dst[1] = cur[2 * k + 1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double p[kPerLane];
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) p[i] = T[lane * 18 + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the next round's writes
+    __builtin_amdgcn_wave_barrier();
+    return wave_compose_same_e(piece_summary(p, e), e);
+}
+
 template <bool HAS_W>
 __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, const double *__restrict__ w,
                                                   long count, long nchunks, int vec, const double *__restrict__ approx,
                                                   const double *__restrict__ goff, Summary *__restrict__ out)
 {
-    // Products are fetched coalesced (lane-interleaved) and handed to the lanes as 16
-    // CONSECUTIVE elements each through LDS; 18-double rows keep the 16-byte reads of the
-    // 16 lanes of a group on distinct banks.
     __shared__ __attribute__((aligned(16))) double tile[4][64 * 18];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // Each wavefront owns a run of consecutive chunks: the chip's reads are then spread over as
@@ -350,23 +473,105 @@ __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, 
             guess_nxt = goff[(c + 1) >> 6] + approx[c + 1];
         }
 
-#pragma unroll
-        for (int k = 0; k < kPerLane / 2; ++k) {
-            const int pos = k * 128 + 2 * lane;
-            double *dst = T + (pos >> 4) * 18 + (pos & 15);
-            dst[0] = cur[2 * k]; dst[1] = cur[2 * k + 1];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double p[kPerLane];
-#pragma unroll
-        for (int i = 0; i < kPerLane; ++i) p[i] = T[lane * 18 + i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the next round's writes
-        __builtin_amdgcn_wave_barrier();
-
-        const Summary s = wave_compose_same_e(piece_summary(p, e), e);
+        const Summary s = chunk_summary(cur, e, T, lane);
         if (lane == 0) out[c] = s;
+    }
+}
+
+// ---- B': chunk summaries from the speculative span sums of the producing kernel --------------------
+// The tiled kernels of the lean schedule (cg_kernels.hpp, NH = 2) summarise every span of kSub products
+// under two hypothesised exponents e0, e0+1 while they produce them, so that the products need neither be
+// stored nor read again.  Here the real guess -- the approximate prefix sum at the span's start, known
+// only now -- picks the hypothesis that matches it; a chunk with a span for which neither does is put on
+// the repair list and summarised from recomputed products by k_sp_fix.  The span sums carry no running
+// extremes; -N and +P (the sums of the negative and of the positive rounded products) bound the running
+// value from below and above whatever the order, which only makes the walk descend a little more often
+// next to a binade boundary.  The same pass writes the next iteration's hypotheses: the lower of the two
+// binades nearest to this iteration's prefix sum at the span.
+// One wavefront per 64 rows of one chunk column (G is a multiple of kChunk here): lane = row, so every
+// access to the by-rows span arrays is a coalesced 512-byte segment.
+__global__ __launch_bounds__(256) void k_sp_select(const double *__restrict__ sub, const double *__restrict__ D0,
+                                                   const double *__restrict__ Q0, const double *__restrict__ D1,
+                                                   double *__restrict__ hyp, double rho, const double *rho_dev, long G,
+                                                   long rows, const double *__restrict__ approx,
+                                                   const double *__restrict__ goff, Summary *__restrict__ chunks,
+                                                   int *__restrict__ fixlist, int *__restrict__ nfix)
+{
+    constexpr int kSpans = kChunk / kSub;
+    if (rho_dev != nullptr) rho = *rho_dev;                     // the prediction the producing kernel scaled the hypotheses by
+    const int lane = threadIdx.x & 63;
+    const long ccols = G / kChunk;                              // chunks per row
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // wavefront -> (row block, chunk column)
+    const long mb = w / ccols, cc = w - mb * ccols;
+    const long m = mb * 64 + lane;
+    if (m >= rows) return;
+    const long c = m * ccols + cc;
+    double guess = goff[c >> 6] + approx[c];
+    const double guess0 = guess;
+    Summary cs = identity();
+    bool miss = false;
+#pragma unroll
+    for (int j = 0; j < kSpans; ++j) {
+        const long idx = (cc * kSpans + j) * rows + m;
+        const int e = exponent_of(guess);
+        const int h = hyp_exponent(hyp[idx], rho);              // what the producing kernel worked with
+        const int sel = (e == kNoExp) ? -1 : e - h;
+        // D under the matching hypothesis; Q bounds the sum of the magnitudes under it (e0: the kernel's bound,
+        // or D itself where no product is negative; e0 + 1: each magnitude at most half as large plus 3/4)
+        double D, Q;
+        if (sel == 0) { D = D0[idx]; Q = (Q0 != nullptr) ? Q0[idx] : D; }
+        else if (sel == 1) { D = D1[idx]; Q = (Q0 != nullptr) ? 0.5 * Q0[idx] + 96.0 : D; }
+        else { D = 0.0; Q = 0.0; miss = true; }
+        Summary sp;
+        sp.D = D;
+        sp.mx = (Q0 != nullptr) ? Q : D;                        // the running value never exceeds the positive part ...
+        sp.mn = (Q0 != nullptr) ? -Q : 0.0;                     // ... nor falls below minus the negative part
+        sp.e = e;
+        // exactness of the kernel's integer sums: the magnitudes under e0 stay below 2^52 in total
+        const double cert = (Q0 != nullptr) ? Q0[idx] : D0[idx];
+        sp.bad = (!(cert < 0x1p52) || D != D) ? 1 : 0;          // D is a NaN where the span held a half-way case
+        cs = compose(cs, sp);
+        hyp[idx] = guess;                                       // next iteration's hypotheses start from this prefix sum
+        guess += sub[idx];
+    }
+    // The bounds above ignore the order of the products inside a span.  Where products of both signs nearly cancel
+    // they are far wider than the true extremes of the running value, and every chunk within that distance of a
+    // binade boundary would send the walk down to the elements.  Judged by the guess (good to a part in 1e12; the
+    // margin is a part in 1e8 of the binade), a chunk that does not clearly stay inside its binade is summarised
+    // once more from recomputed products, with the true extremes, by k_sp_fix; the walk still verifies everything.
+    bool unclear = false;
+    if (!miss && !cs.bad && cs.e != kAnyExp) {
+        const int es = exponent_of(guess0);
+        const double S = (es == kNoExp) ? 0.0 : fabs(ldexp(guess0, 52 - es));
+        const double lo = (guess0 > 0.0) ? S + cs.mn : S - cs.mx, hi = (guess0 > 0.0) ? S + cs.mx : S - cs.mn;
+        unclear = (es != cs.e) || !(lo >= 0x1p52 + 0x1p26) || !(hi <= 0x1p53 - 0x1p26);
+    }
+    if (miss) cs.bad = 1;
+    if (miss || unclear) fixlist[atomicAdd(nfix, 1)] = (int)c;
+    chunks[c] = cs;
+}
+
+// Chunks on the repair list: their products are recomputed from the source and summarised under the guess at
+// the chunk's start, exactly as k_xs_chunk does for stored products.  Persistent wavefronts over the list.
+template <class Src>
+__global__ __launch_bounds__(256) void k_sp_fix(const Src src_in, long count, const int *__restrict__ fixlist,
+                                                const int *__restrict__ nfix, const double *__restrict__ approx,
+                                                const double *__restrict__ goff, Summary *__restrict__ chunks)
+{
+    __shared__ __attribute__((aligned(16))) double T[4][Src::kLds];
+    Src src = src_in;
+    src.prepare();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long nwaves = (long)gridDim.x * 4, wid = (long)blockIdx.x * 4 + wv;
+    const long n = *nfix;
+    for (long i = wid; i < n; i += nwaves) {
+        const long c = fixlist[i];
+        const long lo = c * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
+        double p[kPerLane];
+        src.chunk16(lo, hi, lane, T[wv], p);
+        const int e = exponent_of(goff[c >> 6] + approx[c]);
+        const Summary s = wave_compose_same_e(piece_summary(p, e), e);
+        if (lane == 0) chunks[c] = s;
     }
 }
 
@@ -397,11 +602,12 @@ __device__ __forceinline__ bool holds(const Summary &c, int es, double S, bool n
 
 // The literal recurrence over elements [lo, hi): 64 coalesced products at a time, then 64
 // dependent additions replayed identically by every lane.
-__device__ __forceinline__ double replay(const double *v, const double *w, long lo, long hi, double s, int lane)
+template <class Src>
+__device__ __forceinline__ double replay(const Src &src, long lo, long hi, double s, int lane)
 {
     for (long base = lo; base < hi; base += 64) {
         const long i = base + lane;
-        const double p = (i < hi) ? product(v, w, i) : 0.0;
+        const double p = (i < hi) ? src.product(i) : 0.0;
         const int m = (hi - base < 64) ? (int)(hi - base) : 64;
         if (m == 64) {
 #pragma unroll
@@ -413,50 +619,76 @@ __device__ __forceinline__ double replay(const double *v, const double *w, long 
     return s;
 }
 
+// One step of an ordered inclusive scan over the wavefront by data-parallel moves: `prev` is the triple of
+// the lane the control word names (zeros -- the identity of the composition, since mn <= 0 <= mx always --
+// where there is no such lane or the row is masked off), composed in front of the lane's own.
+#define CG_SCAN_STEP(CTRL, ROW_MASK)                                                                              \
+    do {                                                                                                          \
+        const double pD = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(D), CTRL, ROW_MASK, 0xf, true),   \
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(D), CTRL, ROW_MASK, 0xf, true));  \
+        const double pmn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(mn), CTRL, ROW_MASK, 0xf, true), \
+                                            __builtin_amdgcn_update_dpp(0, __double2loint(mn), CTRL, ROW_MASK, 0xf, true)); \
+        const double pmx = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(mx), CTRL, ROW_MASK, 0xf, true), \
+                                            __builtin_amdgcn_update_dpp(0, __double2loint(mx), CTRL, ROW_MASK, 0xf, true)); \
+        mn = fmin(pmn, pD + mn);                                                                                  \
+        mx = fmax(pmx, pD + mx);                                                                                  \
+        D = pD + D;                                                                                               \
+    } while (0)
+
 // Walk up to 64 summaries held one per lane (`mine`; lanes >= n hold nothing), in order,
 // starting at index `from` from accumulator s.  Returns the index of the first summary
 // that could not be applied (n if all were) and leaves s as the accumulator just before it.
-__device__ __forceinline__ int walk(Summary mine, int n, int from, double &s, int lane)
+// Every summary is first judged on its own against the accumulator's exponent: one that is flagged, or
+// hypothesises another binade, becomes (0, -inf, +inf) and fails the range test wherever it enters the scan;
+// what is scanned is then just the triple (D, mn, mx).
+__device__ __forceinline__ int walk(const Summary &mine, int n, int from, double &s, int lane)
 {
     const int es = exponent_of(s);
     const double S = (es == kNoExp) ? 0.0 : ldexp(s, 52 - es);
     const bool neg_zero = (s == 0.0) && signbit(s);
-    Summary cur = (lane >= from && lane < n) ? mine : identity();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {        // inclusive ordered scan
-        const Summary prev = shfl_up(cur, off);
-        if (lane >= off) cur = compose(prev, cur);
-    }
-    const bool ok = holds(cur, es, S, neg_zero);
-    // validity is monotone along the scan (flags accumulate, extremes only widen)
+    const bool act = (lane >= from) && (lane < n);
+    const bool zeros = mine.e == kAnyExp;             // adding zeros: s + 0 = s, except (-0) + (+0) = +0
+    const bool poison = act && (mine.bad != 0 || (zeros ? neg_zero : (es == kNoExp || mine.e != es)));
+    double D = 0.0, mn = 0.0, mx = 0.0;
+    if (act && !poison && !zeros) { D = mine.D; mn = mine.mn; mx = mine.mx; }
+    if (poison) { mn = -__builtin_inf(); mx = __builtin_inf(); }
+    CG_SCAN_STEP(0x111, 0xf);                         // row_shr:1
+    CG_SCAN_STEP(0x112, 0xf);                         // row_shr:2
+    CG_SCAN_STEP(0x114, 0xf);                         // row_shr:4
+    CG_SCAN_STEP(0x118, 0xf);                         // row_shr:8  -> inclusive scan inside each row of 16 lanes
+    CG_SCAN_STEP(0x142, 0xa);                         // row_bcast:15 into rows 1 and 3
+    CG_SCAN_STEP(0x143, 0xc);                         // row_bcast:31 into rows 2 and 3
+    bool ok;
+    if (es == kNoExp) ok = (mn == 0.0) && (mx == 0.0);    // only zeros can be added to a zero / subnormal / non-finite accumulator
+    else if (S > 0.0) ok = (S + mn >= 0x1p52 + 1.0) && (S + mx <= 0x1p53 - 1.0);
+    else ok = (S + mx <= -(0x1p52 + 1.0)) && (S + mn >= -(0x1p53 - 1.0));
+    // validity is monotone along the scan (extremes only widen)
     const unsigned long long okmask = __ballot(ok);
     const unsigned long long upto = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
     const unsigned long long want = upto & ~((1ull << from) - 1ull);
     const unsigned long long failed = want & ~okmask;
     const int f = failed ? (int)__builtin_ctzll(failed) : n;
     if (f > from) {
-        const double D = __shfl(cur.D, f - 1, 64);
-        const int ce = __shfl(cur.e, f - 1, 64);
-        if (ce != kAnyExp) s = ldexp(S + D, es - 52);   // exact: integers below 2^53
+        const unsigned long long real = __ballot(act && !zeros) & ((f >= 64) ? ~0ull : ((1ull << f) - 1ull));
+        const double Dt = __shfl(D, f - 1, 64);
+        if (real != 0ull && es != kNoExp) s = ldexp(S + Dt, es - 52);   // exact: integers below 2^53
     }
     return f;
 }
+#undef CG_SCAN_STEP
 
 // A chunk whose stored summary does not apply: cut it into 64 pieces of 16 elements (one per
 // lane), summarise the pieces under the accumulator's ACTUAL exponent, apply the longest
 // valid run, replay the one offending piece literally, and repeat with the new exponent.
-__device__ __forceinline__ double refine(const double *v, const double *w, long lo, long hi, double s, int lane)
+template <class Src>
+__device__ __forceinline__ double refine(const Src &src, long lo, long hi, double s, int lane, double *T)
 {
     double p[kPerLane];
-#pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
-        const long idx = lo + (long)lane * kPerLane + i;
-        p[i] = (idx < hi) ? product(v, w, idx) : 0.0;
-    }
+    src.chunk16(lo, hi, lane, T, p);
     int piece = 0;
     for (int round = 0; piece < 64; ++round) {
         if (round >= 8)                              // many ties or crossings: not worth summarising
-            return replay(v, w, lo + (long)piece * kPerLane, hi, s, lane);
+            return replay(src, lo + (long)piece * kPerLane, hi, s, lane);
         const Summary mine = piece_summary(p, exponent_of(s));
         const int f = walk(mine, 64, piece, s, lane);
         if (f >= 64) break;
@@ -471,65 +703,67 @@ __device__ __forceinline__ double refine(const double *v, const double *w, long 
     return s;
 }
 
-// One group (64 chunk summaries) starting from accumulator s.
-__device__ __forceinline__ double walk_group(const double *v, const double *w, long count, const Summary *chunks,
-                                             long nchunks, long g, double s, int lane)
-{
-    const long cb = g * kGroup;
-    const int nc = (nchunks - cb < 64) ? (int)(nchunks - cb) : 64;
-    const Summary cmine = (lane < nc) ? chunks[cb + lane] : identity();
-    int cpos = 0;
-    while (cpos < nc) {
-        const int cf = walk(cmine, nc, cpos, s, lane);
-        if (cf >= nc) break;
-        const long lo = (cb + cf) * kChunk;
-        const long hi = (lo + kChunk < count) ? lo + kChunk : count;
-        s = refine(v, w, lo, hi, s, lane);
-        cpos = cf + 1;
-    }
-    return s;
-}
-
-// Three levels: 64 super-groups (of 64 groups of 64 chunks) are scanned per step; where a
-// summary does not apply the walk descends one level, down to the elements.
-__global__ __launch_bounds__(64) void k_xs_walk(const double *__restrict__ v, const double *__restrict__ w, long count,
+// Two levels: the group summaries are scanned 64 at a time (the next 64 are on their way meanwhile); where one
+// does not apply the walk descends to its 64 chunks, and from a chunk that does not apply to the elements.
+// stats (may be null): [0] groups descended into, [1] chunks taken apart.
+template <class Src>
+__global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                                                 const Summary *__restrict__ chunks, long nchunks,
-                                                const Summary *__restrict__ groups, long ngroups,
-                                                const Summary *__restrict__ supers, long nsupers, double start,
-                                                const double *start_dev, double *result)
+                                                const Summary *__restrict__ groups, long ngroups, double start,
+                                                const double *start_dev, double *result, long *stats)
 {
+    __shared__ __attribute__((aligned(16))) double T[Src::kLds];
+    Src src = src_in;
+    src.prepare();
     const int lane = threadIdx.x;
     double s = (start_dev != nullptr) ? *start_dev : start;
-    for (long sb = 0; sb < nsupers; sb += 64) {
-        const int ns = (nsupers - sb < 64) ? (int)(nsupers - sb) : 64;
-        const Summary smine = (lane < ns) ? supers[sb + lane] : identity();
-        int spos = 0;
-        while (spos < ns) {
-            const int sf = walk(smine, ns, spos, s, lane);
-            if (sf >= ns) break;
-            // super-group sb+sf does not apply as a whole: walk its groups
-            const long gb = (sb + sf) * kGroup;
-            const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
-            const Summary gmine = (lane < ng) ? groups[gb + lane] : identity();
-            int gpos = 0;
-            while (gpos < ng) {
-                const int gf = walk(gmine, ng, gpos, s, lane);
-                if (gf >= ng) break;
-                s = walk_group(v, w, count, chunks, nchunks, gb + gf, s, lane);
-                gpos = gf + 1;
+    long n_groups = 0, n_chunks = 0;
+    Summary nxt = (lane < ngroups) ? groups[lane] : identity();
+    for (long gb = 0; gb < ngroups; gb += 64) {
+        const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
+        const Summary gmine = nxt;
+        if (gb + 64 + lane < ngroups) nxt = groups[gb + 64 + lane];
+        int gpos = 0;
+        while (gpos < ng) {
+            const int gf = walk(gmine, ng, gpos, s, lane);
+            if (gf >= ng) break;
+            // group gb+gf does not apply as a whole: walk its chunks
+            ++n_groups;
+            const long cb = (gb + gf) * kGroup;
+            const int nc = (nchunks - cb < 64) ? (int)(nchunks - cb) : 64;
+            const Summary cmine = (lane < nc) ? chunks[cb + lane] : identity();
+            int cpos = 0;
+            while (cpos < nc) {
+                const int cf = walk(cmine, nc, cpos, s, lane);
+                if (cf >= nc) break;
+                ++n_chunks;
+                const long lo = (cb + cf) * kChunk;
+                const long hi = (lo + kChunk < count) ? lo + kChunk : count;
+                s = refine(src, lo, hi, s, lane, T);
+                cpos = cf + 1;
             }
-            spos = sf + 1;
+            gpos = gf + 1;
         }
     }
-    if (lane == 0) *result = s;
+    if (lane == 0) {
+        *result = s;
+        if (stats != nullptr) { stats[0] = n_groups; stats[1] = n_chunks; }
+    }
 }
 
 // Workspace for `count` elements.
 struct Workspace {
     double *approx = nullptr, *goff = nullptr;
     double *sub = nullptr;                // span sums handed over by the producing kernel (kSub products each)
-    Summary *chunks = nullptr, *groups = nullptr, *supers = nullptr;
+    Summary *chunks = nullptr, *groups = nullptr;
+    long *stats = nullptr;                // what the last walks descended into: [2*which] groups, [2*which+1] chunks
     long cap_chunks = 0;
+    // speculative path (reserve_spec): span sums under two hypotheses, the hypotheses of the two dot products of
+    // an iteration (they persist from one iteration to the next), the repair list
+    double *spD0 = nullptr, *spQ0 = nullptr, *spD1 = nullptr;
+    double *hyp[2] = {nullptr, nullptr};              // last iteration's prefix sum at every span (0 = none yet)
+    int *fixlist = nullptr, *nfix = nullptr;
+    long cap_spec = 0;
 
     static long chunks_for(long count) { return (count + kChunk - 1) / kChunk; }
     hipError_t reserve(long count)
@@ -537,10 +771,11 @@ struct Workspace {
         const long nc = chunks_for(count);
         if (nc <= cap_chunks) return hipSuccess;
         release();
-        const long ng = (nc + kGroup - 1) / kGroup, nsup = (ng + kGroup - 1) / kGroup;
+        const long ng = (nc + kGroup - 1) / kGroup;
         hipError_t e;
         if ((e = hipMalloc(&sub, (size_t)nc * (kChunk / kSub) * sizeof(double))) != hipSuccess) return e;
-        if ((e = hipMalloc(&supers, (size_t)nsup * sizeof(Summary))) != hipSuccess) return e;
+        if ((e = hipMalloc(&stats, 256)) != hipSuccess) return e;
+        if ((e = hipMemset(stats, 0, 256)) != hipSuccess) return e;
         if ((e = hipMalloc(&approx, (size_t)nc * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&goff, (size_t)ng * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&chunks, (size_t)nc * sizeof(Summary))) != hipSuccess) return e;
@@ -548,11 +783,48 @@ struct Workspace {
         cap_chunks = nc;
         return hipSuccess;
     }
+    // Arrays of the speculative path for `count` elements; the hypotheses start as "none" (everything is
+    // repaired the first time round, which also produces real hypotheses for the next).
+    hipError_t reserve_spec(long count)
+    {
+        const long nc = chunks_for(count);
+        if (nc <= cap_spec) return hipSuccess;
+        release_spec();
+        const size_t nspan = (size_t)nc * (kChunk / kSub);
+        hipError_t e;
+        for (double **p : {&spD0, &spQ0, &spD1})
+            if ((e = hipMalloc(p, nspan * sizeof(double))) != hipSuccess) return e;
+        for (int k = 0; k < 2; ++k) {
+            if ((e = hipMalloc(&hyp[k], nspan * sizeof(double))) != hipSuccess) return e;
+            if ((e = hipMemset(hyp[k], 0, nspan * sizeof(double))) != hipSuccess) return e;
+        }
+        if ((e = hipMalloc(&fixlist, (size_t)nc * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMalloc(&nfix, 256)) != hipSuccess) return e;
+        if ((e = hipMemset(nfix, 0, 256)) != hipSuccess) return e;
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+        cap_spec = nc;
+        return hipSuccess;
+    }
+    void forget_hypotheses()                              // a new problem: last solve's prefix sums say nothing about it
+    {
+        if (cap_spec == 0) return;
+        const size_t nspan = (size_t)cap_spec * (kChunk / kSub);
+        for (int k = 0; k < 2; ++k) (void)hipMemset(hyp[k], 0, nspan * sizeof(double));
+        (void)hipDeviceSynchronize();
+    }
+    void release_spec()
+    {
+        (void)hipFree(spD0); (void)hipFree(spQ0); (void)hipFree(spD1);
+        (void)hipFree(hyp[0]); (void)hipFree(hyp[1]); (void)hipFree(fixlist); (void)hipFree(nfix);
+        spD0 = spQ0 = spD1 = nullptr; hyp[0] = hyp[1] = nullptr; fixlist = nullptr; nfix = nullptr;
+        cap_spec = 0;
+    }
     void release()
     {
+        release_spec();
         (void)hipFree(approx); (void)hipFree(goff); (void)hipFree(chunks); (void)hipFree(groups);
-        (void)hipFree(sub); (void)hipFree(supers);
-        approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; sub = nullptr; supers = nullptr;
+        (void)hipFree(sub); (void)hipFree(stats);
+        approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; sub = nullptr; stats = nullptr;
         cap_chunks = 0;
     }
 };
@@ -569,15 +841,16 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
                     double *result, const double *start_dev = nullptr, bool have_sub = false, long sub_G = 0,
                     long sub_rows = 0)
 {
+    const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;   // (null w: v alone)
+    const SrcArrays src{v, w, count > 0 ? count : 0, vec};
     if (count <= 0) {
-        hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, 0L, ws.chunks, 0L, ws.groups, 0L, ws.supers, 0L,
-                           start, start_dev, result);
+        hipLaunchKernelGGL(k_xs_walk<SrcArrays>, dim3(1), dim3(64), 0, s, src, 0L, ws.chunks, 0L, ws.groups, 0L,
+                           start, start_dev, result, (long *)nullptr);
         return;
     }
     const long nc = Workspace::chunks_for(count);
-    const long ng = (nc + kGroup - 1) / kGroup, nsup = (ng + kGroup - 1) / kGroup;
-    const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4), sb = (unsigned)((nsup + 3) / 4);
-    const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;   // (null w: v alone)
+    const long ng = (nc + kGroup - 1) / kGroup;
+    const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4);
     if (have_sub)
         hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub,
                            (count + kSub - 1) / kSub, nc, sub_G, sub_rows, ws.approx);
@@ -591,9 +864,33 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
     else
         hipLaunchKernelGGL(k_xs_chunk<false>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
-    hipLaunchKernelGGL(k_xs_group, dim3(sb), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup);
-    hipLaunchKernelGGL(k_xs_walk, dim3(1), dim3(64), 0, s, v, w, count, ws.chunks, nc, ws.groups, ng, ws.supers, nsup,
-                       start, start_dev, result);
+    hipLaunchKernelGGL(k_xs_walk<SrcArrays>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
+                       start, start_dev, result, ws.stats);
+}
+
+// The same result from the speculative span sums the producing kernel left in the workspace (sub, spD*, spQ*
+// under the hypotheses ws.hyp[which]); `src` recomputes or re-reads single products where the walk or the
+// repair of missed chunks needs them.  The operands are `rows` rows of G products, G a multiple of kChunk.
+// nonneg: every product is >= 0 (a vector with itself), the kernel stored no Q arrays.
+template <class Src>
+inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, long G, long rows, int which, bool nonneg,
+                         const double *rho_dev, double start, double *result)
+{
+    const long count = G * rows;
+    const long nc = Workspace::chunks_for(count);
+    const long ng = (nc + kGroup - 1) / kGroup;
+    const unsigned gb = (unsigned)((ng + 3) / 4);
+    hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub, (count + kSub - 1) / kSub,
+                       nc, G, rows, ws.approx);
+    hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
+    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, (const double *)nullptr, ws.nfix);
+    const long nwave = ((rows + 63) / 64) * (G / kChunk);
+    hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, ws.sub, ws.spD0,
+                       nonneg ? (const double *)nullptr : ws.spQ0, ws.spD1, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
+    hipLaunchKernelGGL(k_sp_fix<Src>, dim3(1024), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
+    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
+    hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
+                       start, (const double *)nullptr, result, ws.stats + 2 * which);
 }
 
 } // namespace exact

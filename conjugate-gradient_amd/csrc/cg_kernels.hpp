@@ -63,6 +63,13 @@ struct Scalars {
     long long u_applied;// iterations whose tau*d has been added into u (lean schedule defers them)
     long long iter_base;// value of `iter` when the current solve began: a solve that continues the previous one
                         // keeps counting (the ring and u_applied use absolute numbers), its history starts here
+    // Strict order, speculative summaries: predicted ratio of the coming dot product to the previous one of its
+    // kind, by which last iteration's prefix sums are scaled into this iteration's exponent hypotheses.
+    //   [0] d.q: tau oscillates with period two while q0 is known, so d.q ~ q0 / tau(two iterations ago);
+    //   [1] g.g: with g' = g + tau*q and g.q = -d.q, g'.g' = tau^2 q.q - q0 up to rounding; q.q rides on pass 1.
+    // Predictions only steer the hypotheses: a bad one costs time, never a bit.
+    double rho[2];
+    double qq;          // q.q of this iteration (fast order; prediction input only)
 };
 
 // ---------------------------------------------------------------- reductions --
@@ -112,6 +119,21 @@ __device__ __forceinline__ double block_sum(double v, double *wave_slots)
     return s;
 }
 
+// The same for a float (one data-parallel move and one add per step).
+__device__ __forceinline__ float wave_sum_unordered_f32(float v)
+{
+#define CG_DPP_ADDF(CTRL, ROW_MASK)                                                                        \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true))
+    CG_DPP_ADDF(0x111, 0xf);
+    CG_DPP_ADDF(0x112, 0xf);
+    CG_DPP_ADDF(0x114, 0xf);
+    CG_DPP_ADDF(0x118, 0xf);
+    CG_DPP_ADDF(0x142, 0xa);
+    CG_DPP_ADDF(0x143, 0xc);
+#undef CG_DPP_ADDF
+    return v;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter (s_waitcnt vmcnt(0)), which would retire every prefetched
 // global load at each row step and serialise the kernel on HBM latency; here the
@@ -155,6 +177,7 @@ struct StencilArgs {
     double *u, *gw;                   // MODE 2: solution and gradient, updated in place
     double *g_out;                    // MODE 4: updated gradient (the other of two gradient buffers)
     double *partials;                 // one partial dot product per tile
+    double *partials2;                // NH > 0, MODE 3: one partial of q.q per tile (prediction input for g.g)
     const Scalars *sc;
     long G;                           // grid side = row length
     long rows;                        // rows in this block
@@ -169,6 +192,15 @@ struct StencilArgs {
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
     Coef9 coef;                       // stencil coefficients
     int store_products;               // WRITE_Q kernels: store d*q (rounded) where q would go
+    // Strict order, speculative summaries (kernels instantiated with NH = 2 only; all arrays in the layout of `sub`):
+    // hyp[span] is last iteration's prefix sum at the span; scaled by the predicted growth sc->rho[hyp_which] it
+    // gives the LOWER of two hypotheses e0, e0+1 (hyp_exponent) for the exponent of the sequential sum when it
+    // reaches the span; the kernel stores, for each hypothesis, the sum D of the span's products rounded to that
+    // binade's ulp (in ulps), and for e0 an upper bound Q0 of the sum of their magnitudes (a NaN D marks a span
+    // with a half-way case).
+    const double *hyp;
+    int hyp_which;                    // 0 = d.q, 1 = g.g
+    double *spD0, *spQ0, *spD1;       // spQ0 is not written when every product is >= 0 (g.g): Q = D there
     double *sub;                      // VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
                                       // (MODE 2, 4, 5: g.g) of every aligned 128-element span (one wavefront's part of a
                                       // row), at sub[(column/128)*rows + r] -- approximate sums for the strict-order dot
@@ -299,6 +331,7 @@ struct RawRow {
     double g[VEC];                    // gradient (MODE 1: operand of the d update; MODE 2: updated)
     double u[VEC];                    // solution (MODE 2)
     double ed, eg;                    // edge column (threads 0 and kBlock-1 only)
+    double hyp;                       // NH > 0: last iteration's prefix sum at this wavefront's span of the row
 };
 
 // One workgroup walks down a column strip of kBlock*VEC columns with a rolling
@@ -321,7 +354,136 @@ struct RawRow {
 // vectors that way, with zero rows where there is no neighbour).  Row addresses are
 // then a pure linear function and the per-row scalar work shrinks to an add; the
 // general form (separate halo pointers, possibly null) serves the stand-alone entry.
-template <int VEC, int MODE, bool WRITE_Q, int PF, bool CONTIG>
+// What a wavefront contributes per row to the strict-order dot product when the exponent of the running sum
+// is only hypothesised (NH = 2): for e0 = the hypothesis and e0 + 1, the integer sum D of its 2 x 64 products
+// rounded to the grid 2^(e-52); Q0, an upper bound of the sum of the magnitudes of the integers under e0
+// (summed in single precision and inflated by more than its rounding error; under e0 + 1 the magnitudes sum to
+// at most Q0/2 + 96); and the plain sum of the products (the approximate span sum).  Sums of integers are exact
+// in any order as long as they stay below 2^53, which Q0 < 2^52 certifies afterwards (every partial sum of the
+// magnitudes is at most their total, and |partial D| <= partial Q); a half-way case anywhere in the span turns
+// that hypothesis' D into a NaN.
+// The sums over the 64 lanes are NOT formed row by row (four dependent data-parallel reductions per row cost
+// more than the rest of the pass): every lane parks its own contribution in LDS, and after eight rows the
+// wavefront adds them up transposed -- lane (r, s) the s-th eighth of row r, three exchange steps between the
+// eighths -- and eight lanes store eight consecutive rows of each span array at once.
+struct SpanEntry {
+    double sub, D0, D1;
+    float qf;
+    int pad;
+};
+#ifndef CG_SPAN_LDS_MIN_MODE
+#define CG_SPAN_LDS_MIN_MODE 4
+#endif
+#ifndef CG_SPAN_GROUPED
+#define CG_SPAN_GROUPED 0
+#endif
+#ifndef CG_SPAN_ROWS
+#define CG_SPAN_ROWS 8
+#endif
+constexpr int kSpanRows = CG_SPAN_ROWS;          // rows per batch (8 or 4)
+constexpr int kSpanStride = 65;       // entries per row in LDS: odd, so that the transposed 16-byte reads spread over the banks
+
+template <int VEC, bool NONNEG>
+__device__ __forceinline__ SpanEntry span_entry(const double (&p)[VEC], int e0, bool &tie0, bool &tie1)
+{
+    SpanEntry s = {0.0, 0.0, 0.0, 0.0f, 0};
+    tie0 = false; tie1 = false;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        s.sub += p[v];
+        const double x0 = ldexp(p[v], 52 - e0);
+        const double r0 = rint(x0);
+        tie0 |= (fabs(x0 - r0) == 0.5);
+        s.D0 += r0;
+        if (!NONNEG) s.qf += (float)fabs(r0);
+        const double x1 = x0 * 0.5;                   // exact (a power of two), or far below 1/2 where it is not
+        const double r1 = rint(x1);
+        tie1 |= (fabs(x1 - r1) == 0.5);
+        s.D1 += r1;
+    }
+    return s;
+}
+
+__device__ __forceinline__ double xor_add(double v, int mask)
+{
+    return v + __shfl_xor(v, mask, 64);
+}
+
+// The same sums for ONE row by data-parallel reductions inside the wavefront (result in lane 63, which stores).
+// Called for several buffered rows in a row, so that their dependent reduction chains interleave.
+template <bool NONNEG>
+__device__ __forceinline__ void span_reduce_store(const SpanEntry &e, bool tie0, bool tie1, long m, bool store,
+                                                  long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
+{
+    const double su = wave_sum_unordered(e.sub);
+    double d0 = wave_sum_unordered(e.D0), d1 = wave_sum_unordered(e.D1);
+    float qf = 0.0f;
+    if (!NONNEG) qf = wave_sum_unordered_f32(e.qf);
+    if (__ballot(tie0) != 0ull) d0 = __builtin_nan("");
+    if (__ballot(tie1) != 0ull) d1 = __builtin_nan("");
+    if (store && (threadIdx.x & 63) == 63) {
+        sub[span_col + m] = su;
+        spD0[span_col + m] = d0;
+        spD1[span_col + m] = d1;
+        if (!NONNEG) spQ0[span_col + m] = (double)qf * (1.0 + 0x1p-12) + 1.0;
+    }
+}
+
+// Adds up a batch of parked rows and stores them.  red: this wavefront's kSpanRows x kSpanStride entries; rows
+// mb .. mb+7 of the block are in the batch, of which [m_lo, m_hi] are to be stored; tiebits: bit r (hypothesis
+// e0) and bit 8+r (e0+1) say that row mb+r held a half-way case.
+template <bool NONNEG>
+__device__ __forceinline__ void span_flush(const SpanEntry *red, long mb, long m_lo, long m_hi, unsigned tiebits,
+                                           long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = lane & (kSpanRows - 1), sg = lane / kSpanRows;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double su = 0.0, d0 = 0.0, d1 = 0.0;
+    float qf = 0.0f;
+    const SpanEntry *row = red + r * kSpanStride + sg * kSpanRows;
+#pragma unroll
+    for (int i = 0; i < kSpanRows; ++i) {
+        const SpanEntry e = row[i];
+        su += e.sub; d0 += e.D0; d1 += e.D1;
+        if (!NONNEG) qf += e.qf;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // all reads done before the next batch's writes
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mask = kSpanRows; mask < 64; mask <<= 1) {          // the parts of a row sit kSpanRows lanes apart
+        su = xor_add(su, mask); d0 = xor_add(d0, mask); d1 = xor_add(d1, mask);
+        if (!NONNEG) qf += __shfl_xor(qf, mask, 64);
+    }
+    const long m = mb + r;
+    if (sg == 0 && m >= m_lo && m <= m_hi) {
+        if ((tiebits >> r) & 1u) d0 = __builtin_nan("");
+        if ((tiebits >> (kSpanRows + r)) & 1u) d1 = __builtin_nan("");
+        sub[span_col + m] = su;
+        spD0[span_col + m] = d0;
+        spD1[span_col + m] = d1;
+        if (!NONNEG) spQ0[span_col + m] = (double)qf * (1.0 + 0x1p-12) + 1.0;   // 2 x 64 roundings of 2^-24 each, far below 2^-12
+    }
+}
+
+constexpr int kHypNone = -30000;      // "no hypothesis": every non-zero product overflows under it, the span is redone later
+
+// The lower of the two exponent hypotheses for a span: `guess` is last iteration's prefix sum at the span, rho the
+// predicted growth of the total.  The two binades nearest to guess*rho are e-1, e when it lies in the lower half
+// (by ratio) of its binade, e, e+1 otherwise.  The kernel that summarises and the kernel that selects both call
+// this with the same arguments.
+__device__ __forceinline__ int hyp_exponent(double guess, double rho)
+{
+    const double v = fabs(guess * rho);
+    if (!(v >= 0x1p-1000) || !(v <= 0x1p1000)) return kHypNone;
+    int ex;
+    const double m = frexp(v, &ex);                   // v = m * 2^ex, m in [0.5, 1)
+    return (m < 0.70710678118654752) ? ex - 2 : ex - 1;
+}
+
+template <int VEC, int MODE, bool WRITE_Q, int PF, bool CONTIG, int NH = 0>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 {
     constexpr bool FUSE_D = (MODE == 1 || MODE >= 3);                // operands are d and g, d' is formed here
@@ -331,6 +493,13 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 
     __shared__ double row_lds[2][W + 2];
     __shared__ double wave_slots[kWaves];
+    // NH > 0: where the per-lane contributions to the span sums wait for their reduction over the wavefront --
+    // the read-only pass keeps those of a whole group of PF rows in registers and reduces them together (measured:
+    // parking them in LDS costs that pass a quarter of its speed), the writing passes park eight rows in LDS.
+    constexpr bool SPAN_LDS = (NH > 0) && (MODE >= CG_SPAN_LDS_MIN_MODE);
+    __shared__ __attribute__((aligned(16))) SpanEntry span_lds[SPAN_LDS ? kWaves * kSpanRows * kSpanStride : 1];
+    SpanEntry *const red = span_lds + (SPAN_LDS ? (threadIdx.x >> 6) * kSpanRows * kSpanStride : 0);
+    unsigned tiebits = 0;
 
     const int tid = threadIdx.x;
     const long nwg = (long)gridDim.x;
@@ -363,6 +532,13 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
         off_qv = (j >= 1 && j <= G - 2) ? (int)(j * 8) : kOOB;
     }
 
+    // NH > 0: this wavefront's column of the span arrays (span index = column block * rows + row)
+    const long span_col = (NH > 0) ? ((c0 >> 7) + __builtin_amdgcn_readfirstlane(tid >> 6)) * a.rows : 0;
+    const __amdgpu_buffer_rsrc_t hyp_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>((NH > 0) ? a.hyp + span_col : nullptr), 0,
+                                          (NH > 0) ? (int)(a.rows * 8) : 0, kRsrcFlags);
+    const double rho = (NH > 0) ? a.sc->rho[a.hyp_which] : 1.0;
+
     double beta = 0.0, tau = 0.0;
     if (FUSE_D) beta = a.sc->beta;
     double tau_prev = 0.0;
@@ -388,6 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
         } else {
             raw.eg = 0.0;
         }
+        if (NH > 0) raw.hyp = buf_load1(hyp_rsrc, (r >= 0 && r < a.rows) ? (int)(r * 8) : kOOB);
         if (MODE == 2 || MODE == 5) {
             const bool own = (r >= r0) && (r < r1);
             BufIO<VEC>::load(row_rsrc_nn(a.u +r * G, own ? rowbytes : 0), off_main, raw.u);
@@ -398,7 +575,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     double up[VEC], mid[VEC], mid_u[VEC], mid_g[VEC], mid_dp[VEC], midL = 0.0, midR = 0.0, upL = 0.0, upR = 0.0;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { up[v] = 0.0; mid[v] = 0.0; mid_u[v] = 0.0; mid_g[v] = 0.0; mid_dp[v] = 0.0; }
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
+    double mid_hyp = 0.0;
 
     RawRow<VEC> ring[PF];
 #pragma unroll
@@ -407,6 +585,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     // Rows r0-1 .. r1 in groups of PF; a group may run past r1, those rows are fully
     // masked (zero loads, dropped stores, zero contributions to the partial sum).
     for (long rb = r0 - 1; rb <= r1; rb += PF) {
+        SpanEntry ent[(NH > 0 && !SPAN_LDS) ? PF : 1];
+        bool ent_t0[(NH > 0 && !SPAN_LDS) ? PF : 1], ent_t1[(NH > 0 && !SPAN_LDS) ? PF : 1];
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const long r = rb + p;
@@ -493,10 +673,29 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 }
                 BufIO<VEC>::store(row_rsrc_nn(a.g_out + m * G, row_own ? rowbytes : 0), off_main, pg);
                 if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
-                    double span = pg[0] * pg[0];
-                    span += pg[VEC - 1] * pg[VEC - 1];
-                    span = wave_sum_unordered(span);
-                    if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
+                    double prod[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) prod[v] = pg[v] * pg[v];
+                    double span = prod[0];
+                    span += prod[VEC - 1];
+                    if (NH == 0) {
+                        span = wave_sum_unordered(span);
+                        if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
+                    } else if (!SPAN_LDS) {
+                        bool t0, t1;
+                        const SpanEntry e = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
+                        span_reduce_store<true>(e, t0, t1, m, row_own, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                    } else if (row_own) {                                      // wave-uniform
+                        bool t0, t1;
+                        constexpr int kRM = kSpanRows - 1;
+                        red[(m & kRM) * kSpanStride + (tid & 63)] = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
+                        tiebits |= ((__ballot(t0) != 0ull) ? 1u : 0u) << (m & kRM);
+                        tiebits |= ((__ballot(t1) != 0ull) ? 1u : 0u) << (kSpanRows + (m & kRM));
+                        if ((m & kRM) == kRM || m == r1 - 1) {
+                            span_flush<true>(red, m & ~(long)kRM, r0, m, tiebits, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                            tiebits = 0;
+                        }
+                    }
                 }
                 if (MODE == 5) {
                     double pu[VEC];
@@ -508,15 +707,37 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     BufIO<VEC>::store(row_rsrc_nn(a.u + m * G, row_own ? rowbytes : 0), off_main, pu);
                 }
             } else {
-                double span = 0.0;
+                double span = 0.0, prod[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    acc += mid[v] * qv[v];                             // q = 0 off the interior
-                    span += mid[v] * qv[v];
+                    prod[v] = mid[v] * qv[v];                          // q = 0 off the interior
+                    acc += prod[v];
+                    if (NH > 0 && MODE == 3) acc2 += qv[v] * qv[v];
+                    span += prod[v];
                 }
                 if (VEC == 2 && a.sub != nullptr) {                                // MODE 0, 1, 3; wave-uniform
-                    span = wave_sum_unordered(span);
-                    if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
+                    if (NH == 0) {
+                        span = wave_sum_unordered(span);
+                        if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
+                    } else if (SPAN_LDS) {
+                        if (row_own) {
+                            bool t0, t1;
+                            constexpr int kRM = kSpanRows - 1;
+                            red[(m & kRM) * kSpanStride + (tid & 63)] = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
+                            tiebits |= ((__ballot(t0) != 0ull) ? 1u : 0u) << (m & kRM);
+                            tiebits |= ((__ballot(t1) != 0ull) ? 1u : 0u) << (kSpanRows + (m & kRM));
+                            if ((m & kRM) == kRM || m == r1 - 1) {
+                                span_flush<false>(red, m & ~(long)kRM, r0, m, tiebits, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                                tiebits = 0;
+                            }
+                        }
+                    } else if (CG_SPAN_GROUPED) {
+                        ent[p] = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), ent_t0[p], ent_t1[p]);
+                    } else {
+                        bool t0, t1;
+                        const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
+                        span_reduce_store<false>(e, t0, t1, m, row_own, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                    }
                 }
                 if (WRITE_Q) {
                     // q itself, or (strict order without a stored q) the rounded products d*q that the
@@ -536,13 +757,27 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
             for (int v = 0; v < VEC; ++v) {
                 up[v] = mid[v]; mid[v] = cur[v]; mid_u[v] = raw.u[v]; mid_g[v] = raw.g[v]; mid_dp[v] = raw.d[v];
             }
+            if (NH > 0) mid_hyp = raw.hyp;
             upL = midL; upR = midR;
             midL = curL; midR = curR;
+        }
+        if (NH > 0 && !SPAN_LDS && CG_SPAN_GROUPED && MODE == 3 && a.sub != nullptr) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {                 // rows rb-1 .. rb+PF-2 were emitted in this group
+                const long m = rb + p - 1;
+                span_reduce_store<false>(ent[p], ent_t0[p], ent_t1[p], m, (m >= r0) && (m < r1), span_col, a.sub, a.spD0,
+                                         a.spQ0, a.spD1);
+            }
         }
     }
 
     const double s = block_sum(acc, wave_slots);
     if (tid == 0) a.partials[tile] = s;
+    if (NH > 0 && MODE == 3) {
+        __syncthreads();
+        const double s2 = block_sum(acc2, wave_slots);
+        if (tid == 0) a.partials2[tile] = s2;
+    }
     }
 }
 
@@ -755,13 +990,24 @@ __device__ __forceinline__ double sum_partials(const double *partials, long coun
     return block_sum(acc, wave_slots);
 }
 
+__device__ __forceinline__ double sane_ratio(double r)
+{
+    return (r > 0x1p-200 && r < 0x1p200) ? r : 1.0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long count,
                                                    const double *strict_src, int nsrc, Scalars *sc, int what,
-                                                   double rtol, double *hist, long hist_cap)
+                                                   double rtol, double *hist, long hist_cap,
+                                                   const double *partials2 = nullptr, long count2 = 0)
 {
     if ((what < 2 || what == 4) && sc->done) return;
     __shared__ double wave_slots[kWaves];
     double s = sum_partials(partials, (strict_src == nullptr && what != 5) ? count : 0, wave_slots);
+    double s2 = 0.0;
+    if (partials2 != nullptr) {                        // q.q partials of the speculative strict pass
+        __syncthreads();
+        s2 = sum_partials(partials2, count2, wave_slots);
+    }
     if (threadIdx.x != 0) return;
     if (strict_src != nullptr) {
         s = strict_src[0];
@@ -771,7 +1017,13 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
         sc->dq = s;
         sc->tau = sc->q0 / s;
         sc->tau_ring[sc->iter & 7] = sc->tau;
+        if (partials2 != nullptr) {
+            sc->qq = s2;
+            sc->rho[1] = sane_ratio((sc->tau * sc->tau * s2 - sc->q0) / sc->q0);
+        }
     } else if (what == 1 || what == 4) {
+        // next iteration's d.q, predicted from the new q0 and the step length of the iteration before this one
+        sc->rho[0] = (sc->iter >= 1) ? sane_ratio(s / sc->tau_ring[(sc->iter - 1) & 7] / sc->dq) : 1.0;
         sc->q1 = s;
         sc->beta = s / sc->q0;
         sc->q0 = s;

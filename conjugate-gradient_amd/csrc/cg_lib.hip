@@ -178,7 +178,7 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
 // Launches the tiled kernel over rows [row_lo, row_hi) of the block (default: all of it) in tiles of
 // t.tile_h rows counted from row_lo; the tiles' partial sums go to a0.partials[part_base ...].
 // Returns the number of tiles launched.
-template <int MODE, bool WRITE_Q>
+template <int MODE, bool WRITE_Q, int NH = 0>
 long launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, long row_lo = 0, long row_hi = -1,
                     long part_base = 0)
 {
@@ -193,8 +193,15 @@ long launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
     const long cap = (MODE == 3) ? 2 * t.max_wgs : t.max_wgs;
     const long nwg = (cap > 0 && cap < a.ntiles_launch) ? cap : a.ntiles_launch;
     const dim3 grid((unsigned)nwg), block(kBlock);
-#define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C>), grid, block, 0, s, a)
-    if (!t.contig) {                  // stand-alone entry point: caller-supplied halo pointers
+#define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C, NH>), grid, block, 0, s, a)
+    if (NH > 0) {                     // speculative strict summaries: 16-byte rows in the context's layout only
+        switch (t.pf_mode[MODE]) {
+        case 1: CG_LAUNCH(2, 1, true); break;
+        case 4: CG_LAUNCH(2, 4, true); break;
+        case 8: CG_LAUNCH(2, 8, true); break;
+        default: CG_LAUNCH(2, 2, true); break;
+        }
+    } else if (!t.contig) {                  // stand-alone entry point: caller-supplied halo pointers
         if (t.vec == 2) CG_LAUNCH(2, 4, false);
         else CG_LAUNCH(1, 4, false);
     } else if (t.vec == 2) {
@@ -263,6 +270,7 @@ struct cg_ctx {
     cg::exact::Workspace xs;              // strict order, parallel evaluation
     cg::Coef9 coef = kPoisson9;           // stencil coefficients (cg_set_stencil)
     int strict_impl = kStrictAuto;
+    int strict_spec = 1;                  // lean schedule, strict order: summarise the products inside the passes
     long strict_blocks = 0;               // s > 1: sum in the layout of the reference on s*s ranks
     double *pack[2] = {nullptr, nullptr}; // one rank's block of v and w, contiguous
     double *block_sums = nullptr;         // its s*s sequential sums
@@ -384,6 +392,15 @@ double *strict_sub(const cg_ctx *c, const TileGeom &t)
     if (!use_parallel_strict(c->strict_impl, c->count)) return nullptr;
     if (t.vec != 2 || c->G % cg::exact::kSub != 0) return nullptr;
     return c->xs.sub;
+}
+
+// Strict order in the lean schedule on one rank: the two passes summarise their products for the sequential sum
+// while they form them (two hypothesised exponents per span, cg_exact.hpp), instead of storing the products
+// d'*q and reading them and g' once more.  Needs rows that are whole chunks.
+bool strict_speculative(const cg_ctx *c, const TileGeom &t)
+{
+    return c->strict_spec && c->nranks == 1 && strict_sub(c, t) != nullptr && c->G % cg::exact::kChunk == 0 &&
+           c->xs.cap_spec >= cg::exact::Workspace::chunks_for(c->count);
 }
 
 int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *partials, long npart,
@@ -537,15 +554,31 @@ int enqueue_lean_iteration(cg_ctx *c)
     // them; the sequential sum is then evaluated from the products alone.
     const bool strict = c->reduce == CG_REDUCE_STRICT;
     double *const sub = strict_sub(c, t);
+    const bool spec = strict && strict_speculative(c, t);
     a.sub = sub;
-    if (strict) {
-        a.q = c->q; a.store_products = 1;
-        launch_stencil<3, true>(tq, a, s);
+    a.spD0 = c->xs.spD0; a.spQ0 = c->xs.spQ0; a.spD1 = c->xs.spD1;
+    if (spec) {
+        a.hyp = c->xs.hyp[0]; a.hyp_which = 0;
+        a.partials2 = c->partials + 2 * c->npart;
+        launch_stencil<3, false, 2>(tq, a, s);
+        HIPCHK(hipGetLastError());
+        cg::exact::SrcStencil src;
+        src.d = c->d[in]; src.g = c->g; src.sc = c->sc; src.coef = c->coef;
+        src.G = c->G; src.rows = c->rows; src.row0 = c->row0; src.count = c->count; src.beta = 0.0;
+        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, c->strict_slot);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_dq, tq.ntiles, c->strict_slot, 1, c->sc, 0, 0.0,
+                           c->hist, c->hist_cap, (const double *)a.partials2, tq.ntiles);
     } else {
-        launch_stencil<3, false>(tq, a, s);
+        if (strict) {
+            a.q = c->q; a.store_products = 1;
+            launch_stencil<3, true>(tq, a, s);
+        } else {
+            launch_stencil<3, false>(tq, a, s);
+        }
+        HIPCHK(hipGetLastError());
+        CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, tq.ntiles, 0, 0.0, sub ? 2 : 0));
     }
-    HIPCHK(hipGetLastError());
-    CGCHK(enqueue_dot_finish(c, strict ? c->q : nullptr, nullptr, p_dq, tq.ntiles, 0, 0.0, sub ? 2 : 0));
     StencilArgs b = a;
     b.store_products = 0;
     b.partials = p_gg;
@@ -555,7 +588,9 @@ int enqueue_lean_iteration(cg_ctx *c)
     b.g_out = c->g_buf[c->gcur ^ 1];
     b.u = c->u;
     const bool with_u = c->lean_pending == 1;             // the previous iteration's u update is outstanding: do both
+    if (spec) { b.hyp = c->xs.hyp[1]; b.hyp_which = 1; }
     auto pass2 = [&](hipStream_t on, const TileGeom &tg, long lo, long hi, long base) -> long {
+        if (spec) return with_u ? launch_stencil<5, false, 2>(tg, b, on, lo, hi, base) : launch_stencil<4, false, 2>(tg, b, on, lo, hi, base);
         return with_u ? launch_stencil<5, false>(tg, b, on, lo, hi, base) : launch_stencil<4, false>(tg, b, on, lo, hi, base);
     };
     if (overlap) {
@@ -579,7 +614,16 @@ int enqueue_lean_iteration(cg_ctx *c)
         HIPCHK(hipGetLastError());
         if (c->multi()) CGCHK(exchange_g_rows(c, s, b.g_out));
     }
-    CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
+    if (spec) {
+        const int vec = ((reinterpret_cast<uintptr_t>(b.g_out)) & 15) == 0 ? 1 : 0;
+        const cg::exact::SrcArrays src{b.g_out, b.g_out, c->count, vec};
+        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, c->strict_slot);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_gg, n_gg, c->strict_slot, 1, c->sc, with_u ? 1 : 4, 0.0,
+                           c->hist, c->hist_cap);
+    } else {
+        CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
+    }
     c->dcur = out;
     c->set_gcur(c->gcur ^ 1);
     c->lean_pending = with_u ? 0 : 1;
@@ -1142,7 +1186,7 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
     alloc(&c->u_alloc, padded); alloc(&c->q_alloc, padded);
     c->front_elems = (size_t)front;
     alloc(&c->g_alloc[0], padded); alloc(&c->d_alloc[0], padded); alloc(&c->d_alloc[1], padded);
-    alloc(&c->partials, 2 * (size_t)c->npart * sizeof(double));
+    alloc(&c->partials, 3 * (size_t)c->npart * sizeof(double));     // d.q | g.g | q.q (strict order, prediction input)
     alloc(&c->strict_slot, 256);
     alloc(reinterpret_cast<double **>(&c->sc), sizeof(Scalars));
     if (rc == CG_OK) {
@@ -1229,6 +1273,7 @@ int cg_set_option(cg_ctx *c, int key, long value)
         if (c->strict_blocks != value) c->live = false;
         c->strict_blocks = value; break;
     case CG_OPT_OVERLAP: c->overlap = value ? 1 : 0; break;
+    case CG_OPT_STRICT_SPEC: c->strict_spec = value ? 1 : 0; break;
     case CG_OPT_COMM_REHEARSAL:
         if (value && c->nranks != 1) return fail(CG_ERR_ARG, "the communication rehearsal is for single-rank contexts");
         c->rehearse = value ? 1 : 0; break;
@@ -1266,6 +1311,27 @@ int cg_get_option(cg_ctx *c, int key, long *value)
     case CG_OPT_STRICT_BLOCKS: *value = c->strict_blocks; break;
     case CG_OPT_TILE_WGS: *value = ctx_geom(c).max_wgs; break;
     case CG_OPT_OVERLAP: *value = c->overlap; break;
+    case CG_OPT_STRICT_SPEC: *value = c->strict_spec; break;
+    case CG_OPT_STRICT_MISSES: {
+        int n = 0;
+        if (c->xs.nfix) {
+            CGCHK(select_device(c->device));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(&n, c->xs.nfix, sizeof n, hipMemcpyDeviceToHost));
+        }
+        *value = n;
+        break;
+    }
+    case CG_OPT_STRICT_EVENTS: {
+        long st[4] = {0, 0, 0, 0};
+        if (c->xs.stats) {
+            CGCHK(select_device(c->device));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(st, c->xs.stats, sizeof st, hipMemcpyDeviceToHost));
+        }
+        *value = st[1] * 1000000L + st[3];              // chunks taken apart: d.q walk * 10^6 + g.g walk
+        break;
+    }
     case CG_OPT_COMM_REHEARSAL: *value = c->rehearse; break;
     default: return fail(CG_ERR_ARG, "unknown option key %d", key);
     }
@@ -1286,6 +1352,7 @@ int cg_init_problem(cg_ctx *c)
     c->live = false;
     c->needs_init = false;
     c->q_valid = true;
+    c->xs.forget_hypotheses();
     HIPCHK(hipMemsetAsync(c->u, 0, bytes, s));           // calloc, cg.c:44
     HIPCHK(hipMemsetAsync(c->q, 0, bytes, s));           // calloc, cg.c:45
     const int fb = flat_blocks(c->count, 0);
@@ -1341,6 +1408,11 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         const long before = c->xs.cap_chunks;
         HIPCHK(c->xs.reserve(c->count));
         if (c->xs.cap_chunks != before) drop_graph(c);      // captured nodes hold the old workspace
+        if (c->strict_spec && c->nranks == 1 && c->effective_schedule() == CG_SCHED_LEAN && c->G % cg::exact::kChunk == 0 &&
+            c->xs.cap_spec < cg::exact::Workspace::chunks_for(c->count)) {
+            HIPCHK(c->xs.reserve_spec(c->count));
+            drop_graph(c);
+        }
     }
     // History buffer (set-up, outside the timed region): room for at least 65536 iterations, so that
     // solves of ordinary length never reallocate it (captured graphs hold its address); at most 2^24.
@@ -1525,9 +1597,17 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     // From here on the vectors and the device scalars are scratch: nothing owed, nothing to continue, and
     // no solve or read-back until cg_init_problem has set the problem up again.
     c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->needs_init = true;
+    bool spec = false;
+    if (sched == CG_SCHED_LEAN && c->reduce == CG_REDUCE_STRICT && c->strict_spec && c->nranks == 1 &&
+        c->G % cg::exact::kChunk == 0 && use_parallel_strict(c->strict_impl, c->count)) {
+        HIPCHK(c->xs.reserve(c->count));
+        HIPCHK(c->xs.reserve_spec(c->count));
+        drop_graph(c);
+        spec = strict_speculative(c, t);
+    }
     Scalars hs;
     memset(&hs, 0, sizeof hs);
-    hs.q0 = 1.0; hs.tau = 0.0; hs.beta = 1.0;
+    hs.q0 = 1.0; hs.tau = 0.0; hs.beta = 1.0; hs.rho[0] = 1.0; hs.rho[1] = 1.0;
     hs.iter = 1LL << 40;                                // every deferred u entry counts as "ran"
     HIPCHK(hipMemcpy(c->sc, &hs, sizeof hs, hipMemcpyHostToDevice));
     double per_point = 0.0;
@@ -1536,12 +1616,18 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
             StencilArgs a = base_args(c, which == 0 ? tq : t);
             const int out = c->dcur ^ 1;
             a.partials = c->partials; a.d_in = c->d[c->dcur]; a.g = c->g;
+            if (spec) {                                    // strict order: the passes with their span summaries
+                a.sub = c->xs.sub; a.spD0 = c->xs.spD0; a.spQ0 = c->xs.spQ0; a.spD1 = c->xs.spD1;
+                a.hyp = c->xs.hyp[which == 0 ? 0 : 1]; a.hyp_which = which == 0 ? 0 : 1;
+                a.partials2 = c->partials + 2 * c->npart;
+            }
             if (which == 0) {
-                launch_stencil<3, false>(tq, a, s);
+                if (spec) launch_stencil<3, false, 2>(tq, a, s);
+                else launch_stencil<3, false>(tq, a, s);
             } else {
                 a.partials = c->partials + c->npart; a.d_out = c->d[out]; a.g_out = c->g_buf[c->gcur ^ 1]; a.u = c->u;
-                if (which == 1) launch_stencil<4, false>(t, a, s);
-                else launch_stencil<5, false>(t, a, s);
+                if (which == 1) { if (spec) launch_stencil<4, false, 2>(t, a, s); else launch_stencil<4, false>(t, a, s); }
+                else { if (spec) launch_stencil<5, false, 2>(t, a, s); else launch_stencil<5, false>(t, a, s); }
                 c->dcur = out; c->set_gcur(c->gcur ^ 1);
             }
         } else if (which == 0) {

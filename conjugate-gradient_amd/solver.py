@@ -150,7 +150,7 @@ class CGSolver:
 
     def configure(self, reduce=None, schedule=None, tile_h=None, graph_iters=None, xcd_remap=None,
                   flat_blocks=None, prefetch=None, strict_impl=None, tile_wgs=None, prefetch_read=None, strict_blocks=None,
-                  overlap=None, comm_rehearsal=None):
+                  overlap=None, comm_rehearsal=None, strict_spec=None):
         if reduce is not None:
             self.set_option(_l.OPT_REDUCE, reduce)
             self.reduce = reduce
@@ -177,6 +177,8 @@ class CGSolver:
             self.set_option(_l.OPT_PREFETCH_READ, prefetch_read)
         if overlap is not None:
             self.set_option(_l.OPT_OVERLAP, 1 if overlap else 0)
+        if strict_spec is not None:
+            self.set_option(_l.OPT_STRICT_SPEC, 1 if strict_spec else 0)
         if comm_rehearsal is not None:
             self.set_option(_l.OPT_COMM_REHEARSAL, 1 if comm_rehearsal else 0)
         return self

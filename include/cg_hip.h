@@ -149,6 +149,14 @@ typedef struct cg_ctx cg_ctx;
                                   utils.c:408-417), the s*s sums combined as MPICH's MPI_Allreduce combines
                                   them (utils.c:380) -- and so reproduces the bits of `mpirun -np s*s ./cg`.
                                   0 or 1 = the single-rank order (default) */
+#define CG_OPT_STRICT_SPEC 15  /* strict order, lean schedule, one rank, rows of a multiple of 1024 points: 1 (default) =
+                                  the passes summarise their products for the sequential sum while they form them, under
+                                  two hypothesised exponents per span (from the previous iteration's prefix sums); spans
+                                  whose hypotheses miss are redone.  0 = store the products and read them again.  Same bits. */
+#define CG_OPT_STRICT_MISSES 16 /* read only (cg_get_option): chunks of 1024 products whose hypotheses missed in the last
+                                  dot product of the last solve and were redone (diagnostic of CG_OPT_STRICT_SPEC) */
+#define CG_OPT_STRICT_EVENTS 17 /* read only: chunks the last solve's final two ordered walks had to take apart element by
+                                  element (binade crossings, half-way cases): 10^6 * (d.q walk) + (g.g walk) */
 #define CG_OPT_OVERLAP     13  /* several ranks, lean schedule: 1 (default) = the new gradient's boundary rows travel on a
                                   second stream while the rows between them are computed; 0 = exchange in line */
 #define CG_OPT_COMM_REHEARSAL 14 /* single-rank context with cg_comm_init: 1 = issue the per-iteration traffic of a

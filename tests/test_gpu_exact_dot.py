@@ -192,3 +192,55 @@ def test_config_4096_to_1e8_is_bit_identical_to_the_reference_on_4_ranks(cg, gol
     assert float(r.q_init).hex() == float.fromhex(rec["q_init_hex"]).hex()
     assert float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex()
     print(f"4096^2 to 1e-8 in the reference's np=4 order: {r.iters} iterations in {r.seconds:.2f} s")
+
+
+# ------------------------- summaries formed inside the producing passes (speculated exponents) ------
+
+@pytest.mark.parametrize("n,iters", [(1023, 61), (2047, 40)])
+def test_speculative_summaries_give_the_bits_of_the_stored_products_path(cg, oracle, n, iters):
+    # lean schedule, strict order: the passes summarise their products under two hypothesised exponents per span
+    # (CG_OPT_STRICT_SPEC, default) instead of storing d'*q and reading it and g' again.  Every bit must agree
+    # with the path that stores the products, for every iteration, and with the CPU restatement.
+    a = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_spec=True).init_problem()
+    b = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_spec=False).init_problem()
+    ra, rb = a.solve(iters), b.solve(iters)
+    assert np.array_equal(bits(a.history(iters)), bits(b.history(iters)))
+    for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+        assert np.array_equal(bits(a.vector(which)), bits(b.vector(which))), which
+    if n <= 1023:
+        assert np.array_equal(bits(a.history(iters)), bits(oracle.cg(n, iters)["hist"]))
+    misses = a.get_option(cg.lib.OPT_STRICT_MISSES)
+    print(f"n={n}: {misses} of {(n + 1) * (n + 1) // 1024} chunks redone in the last dot product")
+
+
+def test_speculative_summaries_continue_across_solves_and_stop_rule(cg, oracle):
+    n = 1023
+    ref = oracle.cg(n, 120)
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, graph_iters=10).init_problem()
+    hist = []
+    for k in (1, 2, 30, 33, 54):
+        s.solve(k)
+        hist.append(s.history(k))
+    assert np.array_equal(bits(np.concatenate(hist)), bits(ref["hist"]))
+    for k, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+        assert np.array_equal(bits(s.vector(which)), bits(ref[k])), k
+    # a new problem on the same context: last solve's hypotheses are forgotten, the bits are the same again
+    s.init_problem()
+    s.solve(120)
+    assert np.array_equal(bits(s.history(120)), bits(ref["hist"]))
+
+
+@pytest.mark.parametrize("coef", [(-1, -2, 6, -2, -1), (-1, -1, -1, -1, 8, -1, -1, -1, -1)])
+def test_speculative_summaries_with_other_coefficients(cg, oracle, coef):
+    # the repair of missed chunks and the walk's descents recompute d'*(A d') from d and g: every coefficient set
+    n, iters = 1023, 40
+    oracle.set_stencil(coef)
+    try:
+        ref = oracle.cg(n, iters)
+    finally:
+        oracle.set_stencil()
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT).set_stencil(coef).init_problem()
+    s.solve(iters)
+    assert np.array_equal(bits(s.history(iters)), bits(ref["hist"]))
+    for k, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+        assert np.array_equal(bits(s.vector(which)), bits(ref[k])), k
