@@ -10,8 +10,8 @@ from .lib import (CGError, REDUCE_FAST, REDUCE_STRICT, SCHED_CLASSIC, SCHED_FUSE
                   VEC_U, VEC_G, VEC_D, VEC_Q, SCHED_BYTES_PER_POINT, SCHED_NAMES, device_count,
                   STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL)
 from .solver import (CGSolver, DeviceVector, SolveResult, init_d, init_g, stencil, dot, axpy, xpay, stencil_noalloc,
-                     verify_u)
+                     verify_u, init_d_block, stencil_block, pack_column)
 
 __all__ = ["lib", "CGError", "CGSolver", "DeviceVector", "SolveResult", "init_d", "init_g", "stencil", "dot",
-           "axpy", "xpay", "stencil_noalloc", "verify_u", "device_count", "REDUCE_FAST", "REDUCE_STRICT", "SCHED_CLASSIC", "SCHED_FUSED",
+           "axpy", "xpay", "stencil_noalloc", "verify_u", "init_d_block", "stencil_block", "pack_column", "device_count", "REDUCE_FAST", "REDUCE_STRICT", "SCHED_CLASSIC", "SCHED_FUSED",
            "SCHED_FUSED_NOQ", "SCHED_LEAN", "STRICT_AUTO", "STRICT_REPLAY", "STRICT_PARALLEL", "VEC_U", "VEC_G", "VEC_D", "VEC_Q", "SCHED_BYTES_PER_POINT", "SCHED_NAMES"]

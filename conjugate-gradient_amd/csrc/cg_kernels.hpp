@@ -1135,6 +1135,66 @@ __global__ __launch_bounds__(kBlock) void k_init_d(double *d, long G, long row0,
     }
 }
 
+// d0 on the rows x cols block whose first point is global (row0, col0) -- one rank's chunk of the reference's
+// sqrt(P) x sqrt(P) decomposition (utils.c:319-337 with carti*chunklength = row0, cartj*chunklength = col0).
+__global__ __launch_bounds__(kBlock) void k_init_d_block(double *d, long G, long row0, long col0, long rows, long cols, double h)
+{
+    const long total = rows * cols;
+    const long stride = (long)gridDim.x * kBlock;
+    for (long k = (long)blockIdx.x * kBlock + threadIdx.x; k < total; k += stride) {
+        const long r = k / cols, c = k - r * cols;
+        const long gi = row0 + r, gj = col0 + c;
+        double val = 0.0;
+        if (!(gi == 0 || gi == G - 1 || gj == 0 || gj == G - 1)) {
+            const double xi = (double)gi * h;
+            const double yj = (double)gj * h;
+            val = 2 * h * h * (xi * (1 - xi) + yj * (1 - yj));
+        }
+        d[k] = val;
+    }
+}
+
+// q = A d on one rank's rows x cols chunk of the reference's two-dimensional decomposition, the whole of
+// apply_stencil_parallel's arithmetic in one kernel: interior points (utils.c:50 -> :15-35), first / last row
+// with the pads received from above / below (utils.c:74-104), first / last column with the pads from the left
+// / right (utils.c:121-151) and the four corner points with two pads each (utils.c:156-218).  A null pad means
+// the chunk touches the global boundary on that side, where q is not written (the reference's loops skip those
+// points the same way).  Five-point sum in the reference's order: up, left, centre, right, down.
+struct BlockArgs {
+    const double *d;                  // rows x cols, row-major
+    const double *top, *bot;          // cols doubles each, or nullptr
+    const double *left, *right;       // rows doubles each, or nullptr
+    double *q;
+    long rows, cols;
+    Coef9 coef;
+};
+
+__global__ __launch_bounds__(kBlock) void k_stencil_block(const BlockArgs a)
+{
+    const long total = a.rows * a.cols;
+    const long stride = (long)gridDim.x * kBlock;
+    for (long k = (long)blockIdx.x * kBlock + threadIdx.x; k < total; k += stride) {
+        const long r = k / a.cols, c = k - r * a.cols;
+        if ((r == 0 && a.top == nullptr) || (r == a.rows - 1 && a.bot == nullptr) || (c == 0 && a.left == nullptr) ||
+            (c == a.cols - 1 && a.right == nullptr))
+            continue;                                  // a point of the global boundary
+        const double up = (r > 0) ? a.d[k - a.cols] : a.top[c];
+        const double down = (r < a.rows - 1) ? a.d[k + a.cols] : a.bot[c];
+        const double lf = (c > 0) ? a.d[k - 1] : a.left[r];
+        const double rt = (c < a.cols - 1) ? a.d[k + 1] : a.right[r];
+        a.q[k] = five_point(a.coef, up, lf, a.d[k], rt, down);
+    }
+}
+
+// Column `col` of a rows x cols row-major array, gathered into contiguous storage: what the reference's strided
+// MPI datatype (MPI_Type_vector(chunklength, 1, chunklength), utils.c:392) does on the sending side.
+__global__ __launch_bounds__(kBlock) void k_pack_column(const double *__restrict__ src, long rows, long cols, long col,
+                                                        double *__restrict__ dst)
+{
+    const long stride = (long)gridDim.x * kBlock;
+    for (long r = (long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += stride) dst[r] = src[r * cols + col];
+}
+
 // g0 = -d0: utils.c:342-350.
 __global__ __launch_bounds__(kBlock) void k_init_g(double *g, const double *d, long count)
 {

@@ -1048,6 +1048,49 @@ int cg_xpay(int device, long count, double b, double *d, const double *g)
     return CG_OK;
 }
 
+int cg_init_d_block(int device, long n, long row0, long col0, long rows, long cols, double *d)
+{
+    if (!d || n < 2 || rows < 1 || cols < 1 || row0 < 0 || col0 < 0 || row0 + rows > n + 1 || col0 + cols > n + 1)
+        return fail(CG_ERR_ARG, "cg_init_d_block: the block must lie inside the (n+1)^2 grid, n >= 2");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    const double h = (double)1 / (double)n;             // utils.c:323
+    hipLaunchKernelGGL(cg::k_init_d_block, dim3(flat_blocks(rows * cols, 0)), dim3(kBlock), 0, sc->stream, d, n + 1, row0, col0,
+                       rows, cols, h);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
+int cg_stencil_block(int device, const int *stencil9, long rows, long cols, const double *d, const double *top,
+                     const double *bot, const double *left, const double *right, double *q)
+{
+    if (!stencil9 || !d || !q || rows < 1 || cols < 1) return fail(CG_ERR_ARG, "cg_stencil_block: bad arguments");
+    if (stencil9[0] != 0 || stencil9[2] != 0 || stencil9[6] != 0 || stencil9[8] != 0)
+        return fail(CG_ERR_ARG, "cg_stencil_block: a chunk with column pads has no corner values (the reference's corner_pad, "
+                    "utils.h:15, is never filled): corner coefficients need the row-block layout");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    cg::BlockArgs a;
+    a.d = d; a.top = top; a.bot = bot; a.left = left; a.right = right; a.q = q; a.rows = rows; a.cols = cols;
+    a.coef = coef_from9(stencil9);
+    hipLaunchKernelGGL(cg::k_stencil_block, dim3(flat_blocks(rows * cols, 0)), dim3(kBlock), 0, sc->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
+int cg_pack_column(int device, long rows, long cols, const double *src, long col, double *dst)
+{
+    if (!src || !dst || rows < 1 || cols < 1 || col < 0 || col >= cols) return fail(CG_ERR_ARG, "cg_pack_column: bad arguments");
+    DeviceScratch *sc;
+    CGCHK(get_scratch(device, &sc));
+    hipLaunchKernelGGL(cg::k_pack_column, dim3(flat_blocks(rows, 0)), dim3(kBlock), 0, sc->stream, src, rows, cols, col, dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sc->stream));
+    return CG_OK;
+}
+
 int cg_verify_u(int device, long n, long row0, long rows, const double *u, double sum_start, double *sum_u_host,
                 double *max_err_host)
 {

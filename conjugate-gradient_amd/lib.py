@@ -61,6 +61,10 @@ SIGNATURES = {
     "cg_stencil9": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p, _dp]),
     "cg_dot": (C.c_int, [C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_double, _dp]),
+    "cg_init_d_block": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p]),
+    "cg_stencil_block": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_pack_column": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p]),
     "cg_verify_u": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_double, _dp, _dp]),
     "cg_stencil_noalloc": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -96,6 +96,21 @@ def stencil(G, row0, rows, d, q, top=None, bot=None, device=0, want_dq=False, co
     return dq.value if want_dq else None
 
 
+def init_d_block(n, row0, col0, rows, cols, d, device=0):
+    """d0 on one chunk of the reference's two-dimensional decomposition (utils.c:319-337)."""
+    _l.check(_l.load().cg_init_d_block(device, n, row0, col0, rows, cols, _p(d)))
+
+
+def stencil_block(rows, cols, d, q, top=None, bot=None, left=None, right=None, device=0, coef5=(-1, -1, 4, -1, -1)):
+    """q = A d on a rows x cols chunk with its four pads (None = global boundary): apply_stencil_parallel, utils.c:38-219."""
+    _l.check(_l.load().cg_stencil_block(device, _stencil9(coef5), rows, cols, _p(d), _p(top), _p(bot), _p(left), _p(right), _p(q)))
+
+
+def pack_column(rows, cols, src, col, dst, device=0):
+    """dst[r] = src[r*cols + col]: the sending side of the reference's strided column datatype (utils.c:392)."""
+    _l.check(_l.load().cg_pack_column(device, rows, cols, _p(src), col, _p(dst)))
+
+
 def stencil_noalloc(G, row0, rows, d, q, top=None, bot=None, device=0, dq=None, stream=None):
     """cg_stencil without any allocation: enqueued on `stream` (None = the null stream), d.q to the device vector `dq`."""
     _l.check(_l.load().cg_stencil_noalloc(device, G, row0, rows, _p(d), _p(top), _p(bot), _p(q), _p(dq), stream))

@@ -85,6 +85,23 @@ int cg_stencil9(int device, const int *stencil9, long G, long row0, long rows, c
  * Replaces the local part of dot, utils.c:368-379.                           */
 int cg_dot(int device, long count, const double *v, const double *w, int strict,
            double start, double *result_host);
+/* ---- the reference's own two-dimensional decomposition (sqrt(P) x sqrt(P) chunks, utils.c:408-417) ----
+ * Operators on one rank's rows x cols chunk, stored row-major like the reference's local arrays.  The fast solve
+ * (cg_solve) uses row blocks; these serve the call-by-call path of include/utils.h, which with them runs the
+ * reference's decomposition as it stands (and, with strict dot products and MPI_Allreduce, gives the bits of
+ * `mpirun -np P ./cg n`).
+ * d0 on the chunk whose first point is global (row0, col0): init_locald's fill loop (utils.c:319-337).      */
+int cg_init_d_block(int device, long n, long row0, long col0, long rows, long cols, double *d);
+/* q = A d on the chunk: apply_stencil_parallel's interior (utils.c:50), edge rows (:74-104), edge columns
+ * (:121-151) and corner points (:156-218).  top / bot: the `cols` values just above / below the chunk, left /
+ * right: the `rows` values beside it (device pointers); NULL = the chunk touches the global boundary there and q
+ * is not written on that edge.  Corner coefficients must be zero here (the reference never fills corner_pad). */
+int cg_stencil_block(int device, const int *stencil9, long rows, long cols, const double *d, const double *top,
+                     const double *bot, const double *left, const double *right, double *q);
+/* dst[r] = src[r*cols + col], r = 0..rows-1: the sending side of the reference's strided column datatype
+ * (MPI_Type_vector, utils.c:392; used at utils.c:261,270).                                                   */
+int cg_pack_column(int device, long rows, long cols, const double *src, long col, double *dst);
+
 /* Checks of a solution block u (global rows [row0, row0+rows) of the (n+1)^2 grid) on the device -- the
  * reference's only inspection hook is the array dump print_local2dmesh (utils.c:352-366), whose one call
  * site is commented out (cg.c:135):

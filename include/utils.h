@@ -55,20 +55,20 @@ typedef struct my_stencil {    /* utils.h:3-7 */
 } stencil_struct;
 
 typedef struct my_d {          /* utils.h:9-16; all DEVICE pointers */
-    double* left_pad;          /* always NULL: no column cuts in a row-block decomposition */
+    double* left_pad;          /* column left of the chunk (two-dimensional layout), NULL at the global boundary and in row blocks */
     double* top_pad;           /* row above the block, NULL at the global boundary (utils.c:290-301) */
     double* locald;
     double* bottom_pad;        /* row below the block, NULL at the global boundary */
-    double* right_pad;         /* always NULL */
+    double* right_pad;         /* column right of the chunk, NULL at the global boundary and in row blocks */
     double* corner_pad;        /* unused, as in the reference */
 } d_struct;
 
 typedef struct my_MPI_Settings {   /* utils.h:18-32 */
-    int cartsize;              /* number of row blocks (= numprocs) */
-    int leftrank;              /* -1 */
-    int toprank;               /* rank-1, or -1 */
-    int bottomrank;            /* rank+1, or -1 */
-    int rightrank;             /* -1 */
+    int cartsize;              /* row blocks: their number (= numprocs); two-dimensional layout: sqrt(numprocs), as utils.c:408 */
+    int leftrank;              /* neighbour ranks, -1 where there is none (utils.c:413-417) */
+    int toprank;
+    int bottomrank;
+    int rightrank;
     int* itags;
     int* jtags;
     MPI_Request* irequests;
@@ -80,9 +80,12 @@ typedef struct my_MPI_Settings {   /* utils.h:18-32 */
     /* ---- appended by this build ---- */
     int device;                /* HIP device of this rank */
     int rank, numprocs;
-    long local_cols;           /* row length n+1 */
-    long local_rows;           /* rows owned by this rank */
+    long local_cols;           /* columns of this rank's chunk (row blocks: the row length n+1) */
+    long local_rows;           /* rows of this rank's chunk */
     long row0;                 /* global index of the first owned row */
+    long col0;                 /* global index of the first owned column (0 in row blocks) */
+    int layout2d;              /* 1: the reference's sqrt(P) x sqrt(P) chunks (CG_LAYOUT=2d), 0: row blocks */
+    double* dev_col[2];        /* device staging for the first / last column (two-dimensional layout) */
     int strict_dot;            /* 1: dot() sums in the reference's exact order (bit-identical, slow) */
     double* host_row[2];       /* pinned staging rows for the MPI halo exchange */
 } MPI_Settings;

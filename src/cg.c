@@ -14,6 +14,9 @@
  *                   scalars, fused kernels, hipGraph
  *   CG_PATH=calls   the reference's own loop structure (cg.c:53-130), one library
  *                   call per step through the utils.h entry points
+ *   CG_LAYOUT=2d    with CG_PATH=calls on P = s*s ranks: the reference's own decomposition into s x s chunks
+ *                   (row and column halos, corner points) instead of row blocks; with CG_STRICT=1 the output is
+ *                   `mpirun -np P ./cg n` of the reference bit for bit
  *   CG_STRICT=1     dot products in the reference's exact summation order
  *                   (bit-identical results, about a third of the fast rate)
  *   CG_STRICT_NP=P  with CG_STRICT=1 on one GPU: the summation layout of the reference run
@@ -198,45 +201,57 @@ int main(int argc, char **argv)
     if (use_calls) {
         /* ---- the reference's loop, one call per step (cg.c:30-130) ---- */
         bytes_per_point = 112;                                         /* six separate passes, as in the reference */
-        MPI_Settings *settings = init_mpi_settings(numprocs, (int)G);
+        const char *lay = getenv("CG_LAYOUT");
+        const int two_d = lay && strcmp(lay, "2d") == 0 && numprocs > 1;
+        int chunk = (int)G;                                            /* row blocks: chunklength is the row length */
+        if (two_d) {
+            const int side = (int)(sqrt((double)numprocs) + 0.5);
+            if (side * side != numprocs) { if (rank == 0) printf("[ERROR] Number of processors must be a perfect square.\n"); return 1; }   /* cg.c:15-18 */
+            if (G % side != 0) { if (rank == 0) printf("[ERROR] Number of points '%d+1' not divisible by the %d x %d processor grid.\n", n, side, side); return 1; }
+            chunk = (int)(G / side);                                   /* cg.c:21-22 */
+        }
+        MPI_Settings *settings = init_mpi_settings(numprocs, chunk);
         device = settings->device;
         settings->strict_dot = strict;
+        const long count_l = settings->local_rows * settings->local_cols;
         stencil_struct *stencil = (stencil_struct *)malloc(sizeof(stencil_struct));
         stencil->size = 3;
         stencil->extent = stencil->size / 2;
         stencil->stencil = (int *)malloc(sizeof(my_stencil));
         memcpy(stencil->stencil, my_stencil, sizeof(my_stencil));
 
-        d_struct *ld = init_locald(n, (int)G, rank, settings);         /* cg.c:41 */
+        d_struct *ld = init_locald(n, chunk, rank, settings);          /* cg.c:41 */
         double *locald = ld->locald;
-        double *localg = init_localg((int)G, locald);                  /* cg.c:43 */
+        double *localg = init_localg(chunk, locald);                   /* cg.c:43 */
         double *localu = NULL, *localq = NULL;
-        CK(cg_malloc(device, count, &localu), "cg_malloc(u)");         /* cg.c:44 */
-        CK(cg_malloc(device, count, &localq), "cg_malloc(q)");         /* cg.c:45 */
+        CK(cg_malloc(device, count_l, &localu), "cg_malloc(u)");       /* cg.c:44 */
+        CK(cg_malloc(device, count_l, &localq), "cg_malloc(q)");       /* cg.c:45 */
 
         double q0, tau, beta;
         barrier();                                                     /* cg.c:50 */
         const double t0 = now_s();
-        dot((int)G, (int)G, localg, localg, settings->cartcomm, &q0);  /* cg.c:55 */
+        dot(chunk, chunk, localg, localg, settings->cartcomm, &q0);    /* cg.c:55 */
         q_init = q1 = q0;
         const double stop = rtol * rtol * q0;
         for (long it = 0; it < iters; ++it) {
             if (numprocs == 1) apply_stencil_serial(n, stencil, locald, localq);                       /* cg.c:58 */
-            else apply_stencil_parallel((int)G, stencil, ld, localq, rank, settings);                  /* cg.c:97 */
-            dot((int)G, (int)G, locald, localq, settings->cartcomm, &tau);                             /* cg.c:61 */
+            else apply_stencil_parallel(chunk, stencil, ld, localq, rank, settings);                   /* cg.c:97 */
+            dot(chunk, chunk, locald, localq, settings->cartcomm, &tau);                               /* cg.c:61 */
             tau = q0 / tau;                                                                            /* cg.c:62 */
-            CK(cg_axpy(device, count, tau, locald, localu), "cg_axpy(u)");                             /* cg.c:63-69 */
-            CK(cg_axpy(device, count, tau, localq, localg), "cg_axpy(g)");                             /* cg.c:70-76 */
-            dot((int)G, (int)G, localg, localg, settings->cartcomm, &q1);                              /* cg.c:79 */
+            CK(cg_axpy(device, count_l, tau, locald, localu), "cg_axpy(u)");                           /* cg.c:63-69 */
+            CK(cg_axpy(device, count_l, tau, localq, localg), "cg_axpy(g)");                           /* cg.c:70-76 */
+            dot(chunk, chunk, localg, localg, settings->cartcomm, &q1);                                /* cg.c:79 */
             beta = q1 / q0;                                                                            /* cg.c:80 */
-            CK(cg_xpay(device, count, beta, locald, localg), "cg_xpay(d)");                            /* cg.c:81-87 */
+            CK(cg_xpay(device, count_l, beta, locald, localg), "cg_xpay(d)");                          /* cg.c:81-87 */
             q0 = q1;                                                                                   /* cg.c:89 */
             done_iters = it + 1;
             if (rtol > 0 && q1 <= stop) break;
         }
         barrier();                                                     /* cg.c:131 */
         runtime = now_s() - t0;
-        inspect(device, rank, numprocs, n, row0, rows, localu, localg, locald);
+        if (!two_d) inspect(device, rank, numprocs, n, row0, rows, localu, localg, locald);
+        else if (rank == 0 && (getenv("CG_VERIFY") || getenv("CG_DUMP")))
+            printf("[INFO] CG_VERIFY / CG_DUMP need whole rows on every rank: not available with CG_LAYOUT=2d\n");
         cg_free(device, localu); cg_free(device, localg); cg_free(device, localq);
         free_struct_elems(stencil, ld, settings);
         free(ld); free(stencil); free(settings);

@@ -7,11 +7,20 @@
  * -- because the signatures have no way to return a status.
  *
  * Build with -DCG_USE_MPI (and an MPI compiler wrapper) for more than one rank:
- * one rank per GPU, row blocks, halo rows staged through the host with
+ * one rank per GPU, halo rows (and columns) staged through the host with
  * MPI_Sendrecv and the dot products completed with MPI_Allreduce, exactly the
- * collective the reference uses (utils.c:380).  This call-by-call path exists
- * for source compatibility; the fast multi-GPU path is cg_solve with
- * cg_comm_init (RCCL, device-resident scalars, hipGraph).
+ * collective the reference uses (utils.c:380).  Two layouts:
+ *   row blocks (default)   chunklength = n+1, rank r owns (n+1)/P whole rows;
+ *   CG_LAYOUT=2d           the reference's own decomposition: P a perfect square,
+ *                          chunklength = (n+1)/sqrt(P), rank r = carti*sqrt(P)+cartj owns
+ *                          the chunk at (carti, cartj) (utils.c:408-417), with row AND
+ *                          column pads, the strided column gathered on the device
+ *                          (utils.c:392) and the corner points done with two pads each
+ *                          (utils.c:156-218).  With CG_STRICT=1 every rank sums its chunk
+ *                          in the reference's order and MPI_Allreduce combines the sums:
+ *                          the bits of `mpirun -np P ./cg n` of the reference itself.
+ * This call-by-call path exists for source compatibility; the fast multi-GPU
+ * path is cg_solve with cg_comm_init (RCCL, device-resident scalars, hipGraph).
  */
 #ifdef CG_USE_MPI
 #include <mpi.h>
@@ -63,23 +72,48 @@ MPI_Settings *init_mpi_settings(int numprocs, int chunklength)
         exit(1);
     }
 #endif
-    if (numprocs < 1 || chunklength % numprocs != 0) {
-        fprintf(stderr, "[ERROR] Number of rows '%d' not divisible by number of processors '%d'.\n", chunklength, numprocs);
-        exit(1);
-    }
+    const char *lay = getenv("CG_LAYOUT");
+    const int two_d = lay && strcmp(lay, "2d") == 0 && numprocs > 1;
     int ndev = 0;
     CK(cg_device_count(&ndev), "cg_device_count");
     if (ndev < 1) { fprintf(stderr, "[ERROR] no GPU visible; this build has no CPU path\n"); exit(1); }
-    s->cartsize = numprocs;
     s->rank = rank;
     s->numprocs = numprocs;
     s->device = rank % ndev;
-    s->local_cols = chunklength;
-    s->local_rows = chunklength / numprocs;
-    s->row0 = (long)rank * s->local_rows;
-    s->toprank = rank > 0 ? rank - 1 : -1;
-    s->bottomrank = rank < numprocs - 1 ? rank + 1 : -1;
-    s->leftrank = s->rightrank = -1;
+    s->layout2d = two_d;
+    if (two_d) {
+        /* utils.c:408-417: a side x side non-periodic cartesian grid, rank = carti*side + cartj */
+        int side = 1;
+        while ((side + 1) * (side + 1) <= numprocs) ++side;
+        if (side * side != numprocs) {
+            fprintf(stderr, "[ERROR] Number of processors must be a perfect square.\n");          /* cg.c:15-18 */
+            exit(1);
+        }
+        const int carti = rank / side, cartj = rank % side;
+        s->cartsize = side;
+        s->local_rows = s->local_cols = chunklength;
+        s->row0 = (long)carti * chunklength;
+        s->col0 = (long)cartj * chunklength;
+        s->toprank = carti > 0 ? rank - side : -1;
+        s->bottomrank = carti < side - 1 ? rank + side : -1;
+        s->leftrank = cartj > 0 ? rank - 1 : -1;
+        s->rightrank = cartj < side - 1 ? rank + 1 : -1;
+        CK(cg_malloc(s->device, chunklength, &s->dev_col[0]), "cg_malloc(column staging)");
+        CK(cg_malloc(s->device, chunklength, &s->dev_col[1]), "cg_malloc(column staging)");
+    } else {
+        if (numprocs < 1 || chunklength % numprocs != 0) {
+            fprintf(stderr, "[ERROR] Number of rows '%d' not divisible by number of processors '%d'.\n", chunklength, numprocs);
+            exit(1);
+        }
+        s->cartsize = numprocs;
+        s->local_cols = chunklength;
+        s->local_rows = chunklength / numprocs;
+        s->row0 = (long)rank * s->local_rows;
+        s->col0 = 0;
+        s->toprank = rank > 0 ? rank - 1 : -1;
+        s->bottomrank = rank < numprocs - 1 ? rank + 1 : -1;
+        s->leftrank = s->rightrank = -1;
+    }
     s->itags = (int *)malloc((size_t)numprocs * sizeof(int));
     s->jtags = (int *)malloc((size_t)numprocs * sizeof(int));
     s->irequests = (MPI_Request *)calloc((size_t)numprocs, sizeof(MPI_Request));
@@ -97,17 +131,25 @@ MPI_Settings *init_mpi_settings(int numprocs, int chunklength)
 d_struct *init_locald(const int n, const int chunklength, const int myrank, MPI_Settings *s)
 {
     (void)myrank;
-    if (chunklength != n + 1) {
-        fprintf(stderr, "[ERROR] row-block build: chunklength must be the row length n+1 = %d (got %d)\n", n + 1, chunklength);
+    if (!s->layout2d && chunklength != n + 1) {
+        fprintf(stderr, "[ERROR] row-block build: chunklength must be the row length n+1 = %d (got %d); "
+                        "CG_LAYOUT=2d selects the reference's sqrt(P) x sqrt(P) chunks\n", n + 1, chunklength);
+        exit(1);
+    }
+    if (s->layout2d && (long)chunklength * s->cartsize != (long)n + 1) {
+        fprintf(stderr, "[ERROR] Number of points '%d+1' not divisible by the %d x %d processor grid.\n", n, s->cartsize, s->cartsize);
         exit(1);
     }
     d_struct *d = (d_struct *)calloc(1, sizeof(d_struct));
     if (!d) { fprintf(stderr, "[ERROR] out of host memory\n"); exit(1); }
-    const long G = s->local_cols, rows = s->local_rows;
-    CK(cg_malloc(s->device, rows * G, &d->locald), "cg_malloc(locald)");
-    if (s->toprank >= 0) CK(cg_malloc(s->device, G, &d->top_pad), "cg_malloc(top_pad)");         /* utils.c:294-301 */
-    if (s->bottomrank >= 0) CK(cg_malloc(s->device, G, &d->bottom_pad), "cg_malloc(bottom_pad)"); /* utils.c:290-293 */
-    CK(cg_init_d(s->device, n, s->row0, rows, d->locald), "cg_init_d");
+    const long cols = s->local_cols, rows = s->local_rows;
+    CK(cg_malloc(s->device, rows * cols, &d->locald), "cg_malloc(locald)");
+    if (s->toprank >= 0) CK(cg_malloc(s->device, cols, &d->top_pad), "cg_malloc(top_pad)");         /* utils.c:294-301 */
+    if (s->bottomrank >= 0) CK(cg_malloc(s->device, cols, &d->bottom_pad), "cg_malloc(bottom_pad)"); /* utils.c:290-293 */
+    if (s->leftrank >= 0) CK(cg_malloc(s->device, rows, &d->left_pad), "cg_malloc(left_pad)");       /* utils.c:310-316 */
+    if (s->rightrank >= 0) CK(cg_malloc(s->device, rows, &d->right_pad), "cg_malloc(right_pad)");    /* utils.c:306-309 */
+    if (s->layout2d) CK(cg_init_d_block(s->device, n, s->row0, s->col0, rows, cols, d->locald), "cg_init_d_block");
+    else CK(cg_init_d(s->device, n, s->row0, rows, d->locald), "cg_init_d");
     return d;
 }
 
@@ -129,38 +171,53 @@ void apply_stencil_serial(int n, stencil_struct *my_stencil, double *d, double *
     CK(cg_stencil9(cur_device(), my_stencil->stencil, G, 0, G, d, NULL, NULL, q, NULL), "cg_stencil9");
 }
 
-/* utils.c:221-274, rows only.  Device rows are staged through the host. */
+/* utils.c:221-274.  Device rows (and, in the two-dimensional layout, columns) are staged through the host. */
+#ifdef CG_USE_MPI
+static void swap_with(MPI_Settings *s, int peer, const double *dev_send, double *dev_recv, long count)
+{
+    MPI_Status st;
+    CK(cg_copy_to_host(s->device, s->host_row[0], dev_send, count), "halo d2h");
+    MPI_Sendrecv(s->host_row[0], (int)count, MPI_DOUBLE, peer, s->itags[s->rank],
+                 s->host_row[1], (int)count, MPI_DOUBLE, peer, s->itags[peer], s->cartcomm, &st);
+    CK(cg_copy_to_device(s->device, dev_recv, s->host_row[1], count), "halo h2d");
+}
+#endif
+
 void exchange_boundaries(const int chunklength, d_struct *ld, const int myrank, MPI_Settings *s)
 {
-    (void)myrank;
+    (void)myrank; (void)chunklength;
 #ifdef CG_USE_MPI
-    const long G = chunklength, rows = s->local_rows;
-    MPI_Status st;
-    if (ld->bottom_pad != NULL) {          /* last row down, neighbour's first row back (utils.c:234-239) */
-        CK(cg_copy_to_host(s->device, s->host_row[0], ld->locald + (rows - 1) * G, G), "halo d2h");
-        MPI_Sendrecv(s->host_row[0], (int)G, MPI_DOUBLE, s->bottomrank, s->itags[s->rank],
-                     s->host_row[1], (int)G, MPI_DOUBLE, s->bottomrank, s->itags[s->bottomrank], s->cartcomm, &st);
-        CK(cg_copy_to_device(s->device, ld->bottom_pad, s->host_row[1], G), "halo h2d");
+    const long cols = s->local_cols, rows = s->local_rows;
+    /* last row down, the lower neighbour's first row back (utils.c:234-239); first row up (utils.c:243-248) */
+    if (ld->bottom_pad != NULL) swap_with(s, s->bottomrank, ld->locald + (rows - 1) * cols, ld->bottom_pad, cols);
+    if (ld->top_pad != NULL) swap_with(s, s->toprank, ld->locald, ld->top_pad, cols);
+    /* last column to the right, first column to the left (utils.c:255-272): the strided column is gathered on
+     * the device (the reference's MPI_Type_vector, utils.c:392) and received contiguously, as there */
+    if (ld->right_pad != NULL) {
+        CK(cg_pack_column(s->device, rows, cols, ld->locald, cols - 1, s->dev_col[0]), "cg_pack_column");
+        swap_with(s, s->rightrank, s->dev_col[0], ld->right_pad, rows);
     }
-    if (ld->top_pad != NULL) {             /* first row up, neighbour's last row back (utils.c:243-248) */
-        CK(cg_copy_to_host(s->device, s->host_row[0], ld->locald, G), "halo d2h");
-        MPI_Sendrecv(s->host_row[0], (int)G, MPI_DOUBLE, s->toprank, s->itags[s->rank],
-                     s->host_row[1], (int)G, MPI_DOUBLE, s->toprank, s->itags[s->toprank], s->cartcomm, &st);
-        CK(cg_copy_to_device(s->device, ld->top_pad, s->host_row[1], G), "halo h2d");
+    if (ld->left_pad != NULL) {
+        CK(cg_pack_column(s->device, rows, cols, ld->locald, 0, s->dev_col[1]), "cg_pack_column");
+        swap_with(s, s->leftrank, s->dev_col[1], ld->left_pad, rows);
     }
 #else
-    (void)chunklength; (void)ld; (void)s;  /* one rank: no neighbours */
+    (void)ld; (void)s;                     /* one rank: no neighbours */
 #endif
 }
 
-/* utils.c:38-219, rows only: exchange, then the stencil over the whole block with its pad rows. */
+/* utils.c:38-219: exchange, then the stencil over the whole chunk with its pads. */
 void apply_stencil_parallel(const int chunklength, stencil_struct *my_stencil, d_struct *ld, double *localq,
                             const int myrank, MPI_Settings *s)
 {
     check_stencil(my_stencil);
     exchange_boundaries(chunklength, ld, myrank, s);
-    CK(cg_stencil9(s->device, my_stencil->stencil, chunklength, s->row0, s->local_rows, ld->locald, ld->top_pad, ld->bottom_pad, localq, NULL),
-       "cg_stencil");
+    if (s->layout2d)
+        CK(cg_stencil_block(s->device, my_stencil->stencil, s->local_rows, s->local_cols, ld->locald, ld->top_pad, ld->bottom_pad,
+                            ld->left_pad, ld->right_pad, localq), "cg_stencil_block");
+    else
+        CK(cg_stencil9(s->device, my_stencil->stencil, chunklength, s->row0, s->local_rows, ld->locald, ld->top_pad, ld->bottom_pad,
+                       localq, NULL), "cg_stencil");
 }
 
 /* utils.c:368-381.  rows*cols is all that matters, as in the reference. */
@@ -169,10 +226,16 @@ void dot(const int rows, const int cols, double *localv, double *localw, MPI_Com
     (void)comm;
     MPI_Settings *s = g_settings;
     const long rr = (s && s->numprocs > 1) ? s->local_rows : rows;
-    const long count = rr * (long)cols;
+    const long count = rr * (long)((s && s->layout2d) ? s->local_cols : cols);
     const int strict = s ? s->strict_dot : 0;
     double local = 0.0;
 #ifdef CG_USE_MPI
+    if (s && s->numprocs > 1 && s->layout2d) {
+        /* the reference's own summation: every rank its chunk (in its exact order when strict), MPI_Allreduce (utils.c:380) */
+        CK(cg_dot(s->device, count, localv, localw, strict, 0.0, &local), "cg_dot");
+        MPI_Allreduce(&local, result, 1, MPI_DOUBLE, MPI_SUM, s->cartcomm);
+        return;
+    }
     if (s && s->numprocs > 1) {
         if (strict) {
             /* one accumulator handed from rank to rank: the np=1 summation order */
@@ -215,9 +278,13 @@ void free_struct_elems(stencil_struct *stencil, d_struct *ld, MPI_Settings *s)
 {
     free(stencil->stencil);
     const int dev = s ? s->device : 0;
+    if (ld->left_pad) cg_free(dev, ld->left_pad);
     if (ld->top_pad) cg_free(dev, ld->top_pad);
     if (ld->locald) cg_free(dev, ld->locald);
     if (ld->bottom_pad) cg_free(dev, ld->bottom_pad);
+    if (ld->right_pad) cg_free(dev, ld->right_pad);
+    if (s->dev_col[0]) cg_free(dev, s->dev_col[0]);
+    if (s->dev_col[1]) cg_free(dev, s->dev_col[1]);
     free(s->itags); free(s->jtags); free(s->irequests); free(s->jrequests);
     free(s->host_row[0]); free(s->host_row[1]);
     if (g_settings == s) g_settings = NULL;

@@ -156,3 +156,26 @@ def test_driver_with_other_stencil_coefficients(golden, path):
     rec = golden[(63, 50, 1, 0.0, (-1, -2, 6, -2, -1))]
     _, m = run(["63", "50"], env={"CG_STRICT": "1", "CG_STENCIL": "-1,-2,6,-2,-1", "CG_PATH": path})
     assert m.group(2) == rec["q1_hex"]
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+@pytest.mark.parametrize("n,iters,np_", [(15, 10, 4), (63, 50, 4), (63, 50, 16), (255, 200, 4), (1023, 200, 4)])
+def test_two_dimensional_layout_reproduces_the_reference_on_np_ranks(golden, n, iters, np_):
+    # The reference's own decomposition for real: np_ processes (sharing the test GPU), sqrt(np_) x sqrt(np_) chunks,
+    # row and column halos, corner points, every rank's chunk summed in the reference's order, MPI_Allreduce on
+    # top -- the output of `mpirun -np np_ ./cg n` of the reference itself, bit for bit.
+    rec = golden[(n, iters, np_, 0.0)]
+    lines, m = run([str(n), str(iters)], env={"CG_PATH": "calls", "CG_LAYOUT": "2d", "CG_STRICT": "1"}, mpi=np_)
+    assert m.group(2) == rec["q1_hex"] and int(m.group(5)) == np_
+    assert lines[0] == "[INFO] norm_g^2 = %.16f" % float.fromhex(rec["q1_hex"])
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+def test_two_dimensional_layout_other_coefficients_and_fast_order(golden):
+    rec = golden[(63, 50, 4, 0.0, (-1, -2, 6, -2, -1))]
+    _, m = run(["63", "50"], env={"CG_PATH": "calls", "CG_LAYOUT": "2d", "CG_STRICT": "1", "CG_STENCIL": "-1,-2,6,-2,-1"}, mpi=4)
+    assert m.group(2) == rec["q1_hex"]
+    rec = golden[(255, 200, 4, 0.0)]
+    _, m = run(["255"], env={"CG_PATH": "calls", "CG_LAYOUT": "2d"}, mpi=4)
+    q1_ref = float.fromhex(rec["q1_hex"])
+    assert abs(float(m.group(1)) - q1_ref) <= 5e-8 * q1_ref

@@ -515,6 +515,37 @@ def test_nine_entries_with_zero_corners_are_the_five_point_results(cg, golden):
         assert np.array_equal(bits(s.vector(which)), bits(want[k])), k
 
 
+# ------------------------------------- chunks of the reference's two-dimensional decomposition -----
+
+@pytest.mark.parametrize("G,side", [(64, 2), (60, 3), (256, 4)])
+def test_chunk_operators_of_the_two_dimensional_layout_bitwise(cg, oracle, rng, G, side):
+    # every chunk of a side x side decomposition: set-up, the strided column, and the stencil with its four pads
+    # (edge rows, edge columns, corner points: utils.c:74-218) against the single-block CPU restatement
+    n, c = G - 1, G // side
+    full = rng.standard_normal((G, G))
+    want_q = oracle.stencil(full)
+    want_d0 = oracle.init_d(n)
+    for ci in range(side):
+        for cj in range(side):
+            r0, c0 = ci * c, cj * c
+            blk = np.ascontiguousarray(full[r0:r0 + c, c0:c0 + c])
+            d = cg.DeviceVector.from_host(blk)
+            pads = {}
+            pads["top"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0 - 1, c0:c0 + c])) if ci > 0 else None
+            pads["bot"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0 + c, c0:c0 + c])) if ci < side - 1 else None
+            pads["left"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0:r0 + c, c0 - 1])) if cj > 0 else None
+            pads["right"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0:r0 + c, c0 + c])) if cj < side - 1 else None
+            q = cg.DeviceVector(c * c)
+            cg.stencil_block(c, c, d, q, **pads)
+            assert np.array_equal(bits(q.to_host().reshape(c, c)), bits(want_q[r0:r0 + c, c0:c0 + c])), (ci, cj)
+            col = cg.DeviceVector(c)
+            cg.pack_column(c, c, d, c - 1, col)
+            assert np.array_equal(bits(col.to_host()), bits(blk[:, -1]))
+            d0 = cg.DeviceVector(c * c)
+            cg.init_d_block(n, r0, c0, c, c, d0)
+            assert np.array_equal(bits(d0.to_host().reshape(c, c)), bits(want_d0[r0:r0 + c, c0:c0 + c])), (ci, cj)
+
+
 # -------------------------------------------------------- solution checks on the device -----
 
 @pytest.mark.parametrize("n,iters", [(15, 10), (255, 200), (1023, 200)])
