@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--n", "--grid-n", dest="n", type=int, default=16383,
                     help="argv n of the reference: grid side is n+1 (--grid-n: the spelling that survives torch.distributed.run)")
     ap.add_argument("--schedule", choices=["classic", "fused", "fused_noq", "lean"], default="lean")
+    ap.add_argument("--reduce", choices=["fast", "strict"], default="fast",
+                    help="reduction order of the timed run: the documented parallel order (default), or the reference's own "
+                         "(one accumulator, index order: bit-identical results)")
     ap.add_argument("--tile-h", type=int, default=0)
     ap.add_argument("--graph-iters", type=int, default=None,
                     help="iterations per captured hipGraph (default: 10 on one GPU; eager launches with RCCL)")
@@ -175,7 +178,8 @@ def main():
     sched = {"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ,
              "lean": cg.SCHED_LEAN}[args.schedule]
     s = cg.CGSolver(n, device=local_rank, row0=rank * rows, rows=rows, rank=rank, nranks=world)
-    s.configure(reduce=cg.REDUCE_FAST, schedule=sched, tile_h=args.tile_h, graph_iters=args.graph_iters, prefetch=args.prefetch)
+    reduce = cg.REDUCE_STRICT if args.reduce == "strict" else cg.REDUCE_FAST
+    s.configure(reduce=reduce, schedule=sched, tile_h=args.tile_h, graph_iters=args.graph_iters, prefetch=args.prefetch)
     transport = "none"
     if world > 1:
         transport, why = args.transport, ""
@@ -250,7 +254,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{G}x{G} fp64 grid, fixed-count CG, 5-point stencil "
                                    f"(BASELINE.json configs[{2 if world == 1 else 3}])",
-                       "grid": G, "rows_per_gpu": rows, "schedule": args.schedule, "reduce": "fast",
+                       "grid": G, "rows_per_gpu": rows, "schedule": args.schedule, "reduce": args.reduce,
                        "bytes_per_point_per_iter": bpp,
                        "graph_iters": args.graph_iters if args.graph_iters is not None else (10 if world == 1 else 0),
                        "transport": transport, "parallelism": f"rowblocks{world}"},
@@ -261,23 +265,41 @@ def main():
         }
     # per-kernel roofline: HIP events on the solver's stream, this run, this GPU (rank 0's row block)
     if rank == 0:
-        kern = {}
         names = {cg.SCHED_CLASSIC: ("stencil", "update", "dupdate"), cg.SCHED_FUSED: ("stencil", "update"),
                  cg.SCHED_FUSED_NOQ: ("stencil", "update"),
                  # lean: pass 1 every iteration; pass 2 alternates between the plain form and the one that
                  # also applies two iterations' u updates
                  cg.SCHED_LEAN: ("pass1_dq", "pass2_g", "pass2_g_u")}[sched]
-        for which, name in enumerate(names):
-            ms, nbytes = s.time_kernel(which, reps=20)
-            share = 0.5 if (sched == cg.SCHED_LEAN and which > 0) else 1.0
-            kern[name] = {"ms": ms, "bytes": nbytes, "gbs": nbytes / ms / 1e6, "launches_per_iter": share}
-        dom = max(kern, key=lambda k: kern[k]["ms"] * kern[k]["launches_per_iter"])
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
-                           "traffic": profiled_traffic(dom, G, args.schedule) if world == 1 else None,
-                           "algorithmic_bytes_per_launch": kern[dom]["bytes"], "ms_per_launch": kern[dom]["ms"]}
-        out["kernels"] = kern
-        out["parity"] = None if (args.no_parity or world > 1) else parity_run(cg, s, n)
+
+        def kernel_roofline(order):
+            kern = {}
+            for which, name in enumerate(names):
+                ms, nbytes = s.time_kernel(which, reps=20)
+                share = 0.5 if (sched == cg.SCHED_LEAN and which > 0) else 1.0
+                kern[name] = {"ms": ms, "bytes": nbytes, "gbs": nbytes / ms / 1e6, "launches_per_iter": share}
+            dom = max(kern, key=lambda k: kern[k]["ms"] * kern[k]["launches_per_iter"])
+            roof = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": kern[dom]["gbs"] / HBM_PEAK_GBS,
+                    "traffic": profiled_traffic(dom, G, args.schedule, order) if world == 1 else None,
+                    "algorithmic_bytes_per_launch": kern[dom]["bytes"], "ms_per_launch": kern[dom]["ms"]}
+            return roof, kern
+
+        out["roofline"], out["kernels"] = kernel_roofline(args.reduce)
+        out["parity"] = None
+        if world == 1 and not args.no_parity and args.reduce == "fast":
+            # the same grid in the reference's summation order (bit-identical to the reference): its rate, and the
+            # roofline of its kernels -- the same passes, which there also summarise their products for the
+            # sequential sum (algorithmic bytes are the schedule's; the summaries add about 1 B per point)
+            out["parity"] = parity_run(cg, s, n)
+            if out["parity"] and "it_per_s" in out["parity"]:
+                s.configure(reduce=cg.REDUCE_STRICT, schedule=-1).init_problem()
+                s.solve(4)
+                roof, kern = kernel_roofline("strict")
+                its_s = out["parity"]["it_per_s"]
+                roof["it_per_s"] = its_s
+                roof["whole_iteration_gbs"] = bpp * rows * G * its_s / 1e9
+                roof["whole_iteration_frac"] = bpp * rows * G * its_s / 1e9 / HBM_PEAK_GBS
+                out["roofline_strict"], out["kernels_strict"] = roof, kern
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(n)
     if world > 1:
         dist.barrier()                       # no rank tears its communicator down while another still solves
