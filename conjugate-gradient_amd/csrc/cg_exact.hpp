@@ -57,7 +57,8 @@ struct Summary {
     double D;         // sum of the rounded addends, in ulps of the hypothesised binade
     double mn, mx;    // extremes of the running value of D (the empty prefix, 0, included)
     int e;            // hypothesised exponent of the accumulator, or kAnyExp
-    int bad;          // the summary must not be used
+    int bad;          // bit 0: the summary must not be used; bits 1..: for a chunk summary, 1 + the slot of the
+                      // product dump that holds the chunk's products (0 = none)
 };
 
 __device__ __forceinline__ Summary identity()
@@ -73,7 +74,7 @@ __device__ __forceinline__ Summary compose(const Summary &a, const Summary &b)
     r.D = a.D + b.D;
     r.mn = fmin(a.mn, a.D + b.mn);
     r.mx = fmax(a.mx, a.D + b.mx);
-    r.bad = a.bad | b.bad | ((a.e != kAnyExp && b.e != kAnyExp && a.e != b.e) ? 1 : 0);
+    r.bad = ((a.bad | b.bad) & 1) | ((a.e != kAnyExp && b.e != kAnyExp && a.e != b.e) ? 1 : 0);
     r.e = (a.e != kAnyExp) ? a.e : b.e;
     return r;
 }
@@ -144,7 +145,7 @@ __device__ __forceinline__ Summary piece_summary(const double (&p)[kPerLane], in
 __device__ __forceinline__ Summary wave_compose_same_e(Summary cur, int e)
 {
     const int lane = threadIdx.x & 63;
-    const bool any_bad = __ballot(cur.bad != 0) != 0ull;
+    const bool any_bad = __ballot((cur.bad & 1) != 0) != 0ull;
     const bool any_real = __ballot(cur.e != kAnyExp) != 0ull;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -648,7 +649,7 @@ __device__ __forceinline__ int walk(const Summary &mine, int n, int from, double
     const bool neg_zero = (s == 0.0) && signbit(s);
     const bool act = (lane >= from) && (lane < n);
     const bool zeros = mine.e == kAnyExp;             // adding zeros: s + 0 = s, except (-0) + (+0) = +0
-    const bool poison = act && (mine.bad != 0 || (zeros ? neg_zero : (es == kNoExp || mine.e != es)));
+    const bool poison = act && ((mine.bad & 1) != 0 || (zeros ? neg_zero : (es == kNoExp || mine.e != es)));
     double D = 0.0, mn = 0.0, mx = 0.0;
     if (act && !poison && !zeros) { D = mine.D; mn = mine.mn; mx = mine.mx; }
     if (poison) { mn = -__builtin_inf(); mx = __builtin_inf(); }
@@ -681,20 +682,24 @@ __device__ __forceinline__ int walk(const Summary &mine, int n, int from, double
 // lane), summarise the pieces under the accumulator's ACTUAL exponent, apply the longest
 // valid run, replay the one offending piece literally, and repeat with the new exponent.
 template <class Src>
-__device__ __forceinline__ double refine(const Src &src, long lo, long hi, double s, int lane, double *T)
+__device__ __forceinline__ double refine(const Src &src, long lo, long hi, double s, int lane, double *T, long *tally)
 {
     double p[kPerLane];
     src.chunk16(lo, hi, lane, T, p);
     int piece = 0;
     for (int round = 0; piece < 64; ++round) {
-        if (round >= 8)                              // many ties or crossings: not worth summarising
-            return replay(src, lo + (long)piece * kPerLane, hi, s, lane);
-        const Summary mine = piece_summary(p, exponent_of(s));
-        const int f = walk(mine, 64, piece, s, lane);
-        if (f >= 64) break;
+        int f = piece;                               // after many crossings or ties: stop summarising, one piece at a time
+        if (round < 24) {
+            const Summary mine = piece_summary(p, exponent_of(s));
+            f = walk(mine, 64, piece, s, lane);
+            if (f >= 64) break;
+            ++tally[0];
+        } else {
+            ++tally[1];
+        }
         const long first = lo + (long)f * kPerLane;
 #pragma unroll
-        for (int i = 0; i < kPerLane; ++i) {
+        for (int i = 0; i < kPerLane; ++i) {         // the offending piece, literally, from the registers of lane f
             const double pi = __shfl(p[i], f, 64);
             if (first + i < hi) s += pi;
         }
@@ -705,7 +710,8 @@ __device__ __forceinline__ double refine(const Src &src, long lo, long hi, doubl
 
 // Two levels: the group summaries are scanned 64 at a time (the next 64 are on their way meanwhile); where one
 // does not apply the walk descends to its 64 chunks, and from a chunk that does not apply to the elements.
-// stats (may be null): [0] groups descended into, [1] chunks taken apart.
+// stats (may be null): [0] groups descended into, [1] chunks taken apart, [2] rounds of piece summaries inside
+// them, [3] pieces replayed without summarising.
 template <class Src>
 __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                                                 const Summary *__restrict__ chunks, long nchunks,
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
     src.prepare();
     const int lane = threadIdx.x;
     double s = (start_dev != nullptr) ? *start_dev : start;
-    long n_groups = 0, n_chunks = 0;
+    long n_groups = 0, n_chunks = 0, tally[2] = {0, 0};
     Summary nxt = (lane < ngroups) ? groups[lane] : identity();
     for (long gb = 0; gb < ngroups; gb += 64) {
         const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                 ++n_chunks;
                 const long lo = (cb + cf) * kChunk;
                 const long hi = (lo + kChunk < count) ? lo + kChunk : count;
-                s = refine(src, lo, hi, s, lane, T);
+                s = refine(src, lo, hi, s, lane, T, tally);
                 cpos = cf + 1;
             }
             gpos = gf + 1;
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
     }
     if (lane == 0) {
         *result = s;
-        if (stats != nullptr) { stats[0] = n_groups; stats[1] = n_chunks; }
+        if (stats != nullptr) { stats[0] = n_groups; stats[1] = n_chunks; stats[2] = tally[0]; stats[3] = tally[1]; }
     }
 }
 
@@ -756,7 +762,7 @@ struct Workspace {
     double *approx = nullptr, *goff = nullptr;
     double *sub = nullptr;                // span sums handed over by the producing kernel (kSub products each)
     Summary *chunks = nullptr, *groups = nullptr;
-    long *stats = nullptr;                // what the last walks descended into: [2*which] groups, [2*which+1] chunks
+    long *stats = nullptr;                // what the last walks did: [4*which + 0..3] groups, chunks, rounds, blind pieces
     long cap_chunks = 0;
     // speculative path (reserve_spec): span sums under two hypotheses, the hypotheses of the two dot products of
     // an iteration (they persist from one iteration to the next), the repair list
@@ -890,7 +896,7 @@ inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, lon
     hipLaunchKernelGGL(k_sp_fix<Src>, dim3(1024), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
     hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, (const double *)nullptr, result, ws.stats + 2 * which);
+                       start, (const double *)nullptr, result, ws.stats + 4 * which);
 }
 
 } // namespace exact
