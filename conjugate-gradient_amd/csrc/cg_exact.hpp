@@ -577,15 +577,53 @@ __global__ __launch_bounds__(256) void k_sp_fix(const Src src_in, long count, co
 }
 
 // ---- C: groups of 64 chunk summaries -------------------------------------------------
+// The walk (D) is one wavefront, and what it spends its time on is waiting: for the chunk summaries of a group
+// it has to descend into, for the operands of a chunk it has to take apart.  Which groups and chunks those will
+// be is known beforehand almost surely -- the approximate prefix sums that steered the hypotheses also say
+// where the accumulator changes its binade -- so the kernels that produce the summaries mark them, the plan
+// (k_xs_plan) lists the marked chunks in order and stages their products, and the walk fetches one entry ahead.
+// A wrong mark costs time only: the walk judges every summary by the true accumulator.
+constexpr int kPlanCap = 1024;                  // chunks whose products are staged for the walk (8 KiB each)
+constexpr double kPlanMargin = 0x1p26;          // ulps; the approximate prefix sums are far more accurate than that
+constexpr int kPlanBlocks = 32;                 // workgroups that stage them
+constexpr int kMarkBit = 2;                     // Summary::bad of a group summary: the group is expected not to apply
+
+// Will the walk, arriving with an accumulator close to `guess`, probably reject this summary?
+__device__ __forceinline__ bool likely_fails(const Summary &c, double guess)
+{
+    if (c.bad & 1) return true;
+    if (c.e == kAnyExp) return false;
+    const int es = exponent_of(guess);
+    if (es == kNoExp || c.e != es) return true;
+    const double S = fabs(ldexp(guess, 52 - es));
+    const double lo = (guess > 0.0) ? S + c.mn : S - c.mx, hi = (guess > 0.0) ? S + c.mx : S - c.mn;
+    return !(lo >= 0x1p52 + kPlanMargin) || !(hi <= 0x1p53 - kPlanMargin);
+}
+
+// marks (may be null): per group, bit c set = chunk c of the group is expected to be taken apart; the group's own
+// expectation goes into bit kMarkBit of its summary's `bad`.  approx / goff: exclusive prefix of the approximate
+// chunk sums inside the group / approximate accumulator at the group's start.
 __global__ __launch_bounds__(256) void k_xs_group(const Summary *__restrict__ in, long nin, Summary *__restrict__ out,
-                                                  long nout)
+                                                  long nout, const double *__restrict__ approx,
+                                                  const double *__restrict__ goff, unsigned long long *__restrict__ marks)
 {
     const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nout) return;
     const long i = g * kGroup + lane;
-    Summary s = (i < nin) ? in[i] : identity();
-    s = wave_compose(s);
+    const Summary mine = (i < nin) ? in[i] : identity();
+    Summary s = wave_compose(mine);
+    if (marks != nullptr) {
+        const double g0 = goff[g];
+        const bool sus = (i < nin) && likely_fails(mine, g0 + approx[i]);
+        unsigned long long m = __ballot(sus);
+        if (lane == 0) {
+            const bool gs = likely_fails(s, g0);
+            if (gs && m == 0ull) m = 1ull;          // descended into for another reason: its summaries are worth fetching anyway
+            marks[g] = gs ? m : 0ull;
+            s.bad = (s.bad & 1) | (gs ? kMarkBit : 0);
+        }
+    }
     if (lane == 0) out[g] = s;
 }
 
@@ -620,28 +658,20 @@ __device__ __forceinline__ double replay(const Src &src, long lo, long hi, doubl
     return s;
 }
 
-// One step of an ordered inclusive scan over the wavefront by data-parallel moves: `prev` is the triple of
-// the lane the control word names (zeros -- the identity of the composition, since mn <= 0 <= mx always --
-// where there is no such lane or the row is masked off), composed in front of the lane's own.
+// One step of an inclusive prefix sum over the wavefront by data-parallel moves: the lane the control word names
+// contributes its running sum (zero where there is no such lane or the row is masked off).
 #define CG_SCAN_STEP(CTRL, ROW_MASK)                                                                              \
-    do {                                                                                                          \
-        const double pD = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(D), CTRL, ROW_MASK, 0xf, true),   \
-                                           __builtin_amdgcn_update_dpp(0, __double2loint(D), CTRL, ROW_MASK, 0xf, true));  \
-        const double pmn = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(mn), CTRL, ROW_MASK, 0xf, true), \
-                                            __builtin_amdgcn_update_dpp(0, __double2loint(mn), CTRL, ROW_MASK, 0xf, true)); \
-        const double pmx = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(mx), CTRL, ROW_MASK, 0xf, true), \
-                                            __builtin_amdgcn_update_dpp(0, __double2loint(mx), CTRL, ROW_MASK, 0xf, true)); \
-        mn = fmin(pmn, pD + mn);                                                                                  \
-        mx = fmax(pmx, pD + mx);                                                                                  \
-        D = pD + D;                                                                                               \
-    } while (0)
+    D += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(D), CTRL, ROW_MASK, 0xf, true),           \
+                          __builtin_amdgcn_update_dpp(0, __double2loint(D), CTRL, ROW_MASK, 0xf, true))
 
 // Walk up to 64 summaries held one per lane (`mine`; lanes >= n hold nothing), in order,
 // starting at index `from` from accumulator s.  Returns the index of the first summary
 // that could not be applied (n if all were) and leaves s as the accumulator just before it.
 // Every summary is first judged on its own against the accumulator's exponent: one that is flagged, or
-// hypothesises another binade, becomes (0, -inf, +inf) and fails the range test wherever it enters the scan;
-// what is scanned is then just the triple (D, mn, mx).
+// hypothesises another binade, counts as (0, -inf, +inf) and fails the range test.  Only the sums D are scanned:
+// with E the sum of the D before a lane, that lane's summary applies iff the running value stays in range
+// throughout it, S + E + mn and S + E + mx, and the walk stops at the first lane where it does not.  Up to there
+// every partial sum is a difference of two running values inside one binade, an integer below 2^52: exact.
 __device__ __forceinline__ int walk(const Summary &mine, int n, int from, double &s, int lane)
 {
     const int es = exponent_of(s);
@@ -650,47 +680,74 @@ __device__ __forceinline__ int walk(const Summary &mine, int n, int from, double
     const bool act = (lane >= from) && (lane < n);
     const bool zeros = mine.e == kAnyExp;             // adding zeros: s + 0 = s, except (-0) + (+0) = +0
     const bool poison = act && ((mine.bad & 1) != 0 || (zeros ? neg_zero : (es == kNoExp || mine.e != es)));
-    double D = 0.0, mn = 0.0, mx = 0.0;
-    if (act && !poison && !zeros) { D = mine.D; mn = mine.mn; mx = mine.mx; }
-    if (poison) { mn = -__builtin_inf(); mx = __builtin_inf(); }
+    const bool real = act && !poison && !zeros;
+    double D = real ? mine.D : 0.0;
+    const double own = D;
     CG_SCAN_STEP(0x111, 0xf);                         // row_shr:1
     CG_SCAN_STEP(0x112, 0xf);                         // row_shr:2
     CG_SCAN_STEP(0x114, 0xf);                         // row_shr:4
-    CG_SCAN_STEP(0x118, 0xf);                         // row_shr:8  -> inclusive scan inside each row of 16 lanes
+    CG_SCAN_STEP(0x118, 0xf);                         // row_shr:8  -> inclusive inside each row of 16 lanes
     CG_SCAN_STEP(0x142, 0xa);                         // row_bcast:15 into rows 1 and 3
     CG_SCAN_STEP(0x143, 0xc);                         // row_bcast:31 into rows 2 and 3
+    const double E = D - own;
+    const double lo = S + (E + (real ? mine.mn : 0.0)), hi = S + (E + (real ? mine.mx : 0.0));
     bool ok;
-    if (es == kNoExp) ok = (mn == 0.0) && (mx == 0.0);    // only zeros can be added to a zero / subnormal / non-finite accumulator
-    else if (S > 0.0) ok = (S + mn >= 0x1p52 + 1.0) && (S + mx <= 0x1p53 - 1.0);
-    else ok = (S + mx <= -(0x1p52 + 1.0)) && (S + mn >= -(0x1p53 - 1.0));
-    // validity is monotone along the scan (extremes only widen)
+    if (es == kNoExp) ok = !real;                         // only zeros can be added to a zero / subnormal / non-finite accumulator
+    else if (S > 0.0) ok = (lo >= 0x1p52 + 1.0) && (hi <= 0x1p53 - 1.0);
+    else ok = (hi <= -(0x1p52 + 1.0)) && (lo >= -(0x1p53 - 1.0));
+    ok = ok && !poison;
     const unsigned long long okmask = __ballot(ok);
     const unsigned long long upto = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
     const unsigned long long want = upto & ~((1ull << from) - 1ull);
     const unsigned long long failed = want & ~okmask;
     const int f = failed ? (int)__builtin_ctzll(failed) : n;
     if (f > from) {
-        const unsigned long long real = __ballot(act && !zeros) & ((f >= 64) ? ~0ull : ((1ull << f) - 1ull));
+        const unsigned long long any_real = __ballot(real) & ((f >= 64) ? ~0ull : ((1ull << f) - 1ull));
         const double Dt = __shfl(D, f - 1, 64);
-        if (real != 0ull && es != kNoExp) s = ldexp(S + Dt, es - 52);   // exact: integers below 2^53
+        if (any_real != 0ull && es != kNoExp) s = ldexp(S + Dt, es - 52);   // exact: integers below 2^53
     }
     return f;
 }
 #undef CG_SCAN_STEP
 
-// A chunk whose stored summary does not apply: cut it into 64 pieces of 16 elements (one per
-// lane), summarise the pieces under the accumulator's ACTUAL exponent, apply the longest
-// valid run, replay the one offending piece literally, and repeat with the new exponent.
-template <class Src>
-__device__ __forceinline__ double refine(const Src &src, long lo, long hi, double s, int lane, double *T, long *tally)
+// Piece summaries of a staged chunk under the three binades around the one its approximate prefix sum predicts
+// (e_g - 1, e_g, e_g + 1), as the plan prepares them: what refine would otherwise compute on the spot, twice per
+// chunk as a rule (the binade the accumulator arrives in, and the one it leaves in).
+struct Pieces {
+    double D[3], mn[3], mx[3];
+    int flags;                                        // bit h: unusable under hypothesis h; bit 3: the piece holds zeros only
+};
+constexpr int kPieceDoubles = 10;                     // per lane: 3 x (D, mn, mx) and the flags
+constexpr int kEntry = kChunk + 64 * kPieceDoubles + 4;   // doubles per entry of the plan: products, pieces, a stretch summary
+
+__device__ __forceinline__ Summary piece_of(const Pieces &q, int h, int e)
 {
-    double p[kPerLane];
-    src.chunk16(lo, hi, lane, T, p);
+    Summary m;
+    if (q.flags & 8) return identity();
+    m.D = (h == 0) ? q.D[0] : (h == 1) ? q.D[1] : q.D[2];
+    m.mn = (h == 0) ? q.mn[0] : (h == 1) ? q.mn[1] : q.mn[2];
+    m.mx = (h == 0) ? q.mx[0] : (h == 1) ? q.mx[1] : q.mx[2];
+    m.e = e;
+    m.bad = (q.flags >> h) & 1;
+    return m;
+}
+
+// A chunk whose stored summary does not apply, its products p held as 16 consecutive elements per lane (one
+// piece each): summarise the pieces under the accumulator's ACTUAL exponent (or take the prepared summaries when
+// that exponent is one of the three around e_g; e_g = kNoExp: nothing prepared), apply the longest valid run,
+// replay the one offending piece literally, and repeat with the new exponent.
+__device__ __forceinline__ double refine(const double (&p)[kPerLane], const Pieces &pre, int e_g, long lo, long hi,
+                                         double s, int lane, long *tally)
+{
     int piece = 0;
     for (int round = 0; piece < 64; ++round) {
         int f = piece;                               // after many crossings or ties: stop summarising, one piece at a time
         if (round < 24) {
-            const Summary mine = piece_summary(p, exponent_of(s));
+            const int es = exponent_of(s);
+            const int h = es - e_g + 1;
+            Summary mine;
+            if (e_g != kNoExp && es != kNoExp && h >= 0 && h <= 2) mine = piece_of(pre, h, es);    // wave-uniform
+            else mine = piece_summary(p, es);
             f = walk(mine, 64, piece, s, lane);
             if (f >= 64) break;
             ++tally[0];
@@ -708,52 +765,285 @@ __device__ __forceinline__ double refine(const Src &src, long lo, long hi, doubl
     return s;
 }
 
-// Two levels: the group summaries are scanned 64 at a time (the next 64 are on their way meanwhile); where one
-// does not apply the walk descends to its 64 chunks, and from a chunk that does not apply to the elements.
-// stats (may be null): [0] groups descended into, [1] chunks taken apart, [2] rounds of piece summaries inside
-// them, [3] pieces replayed without summarising.
+// Ordered composition of summaries arr[lo .. hi) by one wavefront (result in every lane).
+__device__ __forceinline__ Summary range_compose(const Summary *__restrict__ arr, long lo, long hi, int lane)
+{
+    Summary acc = identity();
+    for (long i = lo; i < hi; i += 64) {
+        Summary m = (i + lane < hi) ? arr[i + lane] : identity();
+        m = wave_compose(m);
+        m.D = __shfl(m.D, 0, 64); m.mn = __shfl(m.mn, 0, 64); m.mx = __shfl(m.mx, 0, 64);
+        m.e = __shfl(m.e, 0, 64); m.bad = __shfl(m.bad, 0, 64);
+        acc = compose(acc, m);
+    }
+    return acc;
+}
+
+// Summary of the chunks [a, b) from the three levels: chunks at the ragged ends, whole groups, whole groups of
+// groups in the middle.
+__device__ __forceinline__ Summary stretch_summary(const Summary *__restrict__ chunks, const Summary *__restrict__ groups,
+                                                   const Summary *__restrict__ supers, long a, long b, int lane)
+{
+    if (a >= b) return identity();
+    const long ga = (a + kGroup - 1) / kGroup, gb = b / kGroup;         // whole groups [ga, gb)
+    if (ga >= gb) return range_compose(chunks, a, b, lane);             // fewer than 128 chunks, no whole group among them
+    Summary acc = range_compose(chunks, a, ga * kGroup, lane);
+    const long sa = (ga + kGroup - 1) / kGroup, sb = gb / kGroup;       // whole groups of groups [sa, sb)
+    if (sa >= sb) {
+        acc = compose(acc, range_compose(groups, ga, gb, lane));
+    } else {
+        acc = compose(acc, range_compose(groups, ga, sa * kGroup, lane));
+        acc = compose(acc, range_compose(supers, sa, sb, lane));
+        acc = compose(acc, range_compose(groups, sb * kGroup, gb, lane));
+    }
+    return compose(acc, range_compose(chunks, gb * kGroup, b, lane));
+}
+
+// The plan: the marked chunks (k_xs_group) in index order, at most kPlanCap of them, and for each an entry of
+// kEntry doubles in `dump`: the kChunk products of chunk plist[k], lane-major as chunk16 delivers them; per lane
+// the prepared piece summaries (Pieces); and the summary of the whole stretch of chunks between the previous
+// entry's chunk and this one (entry n: the stretch after the last marked chunk) -- what the walk applies in one
+// step when nothing unforeseen happens in between.  pexp[k] is the entry's e_g.  Every workgroup compacts the
+// marks for itself (a few microseconds; saves a launch and a grid-wide hand-over), workgroup 0 publishes the
+// list, and all of them share the staging.
+template <class Src>
+__global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, const Summary *__restrict__ chunks,
+                                                 long nchunks, const Summary *__restrict__ groups,
+                                                 const Summary *__restrict__ supers,
+                                                 const unsigned long long *__restrict__ marks,
+                                                 long ngroups, const double *__restrict__ approx,
+                                                 const double *__restrict__ goff, int *__restrict__ plist,
+                                                 int *__restrict__ pexp, int *__restrict__ pn, double *__restrict__ dump)
+{
+    __shared__ __attribute__((aligned(16))) double T[4][Src::kLds];
+    __shared__ int clist[kPlanCap];
+    __shared__ int wave_tot[4];
+    Src src = src_in;
+    src.prepare();
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long per = (ngroups + 255) / 256;
+    const long g_lo = (long)t * per, g_hi = (g_lo + per < ngroups) ? g_lo + per : ngroups;
+    int mine = 0;
+    for (long g = g_lo; g < g_hi; ++g) mine += __popcll(marks[g]);
+    int inc = mine;                                  // inclusive scan over the workgroup
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += up;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    int pos = inc - mine, total = 0;
+    for (int k = 0; k < 4; ++k) { if (k < wv) pos += wave_tot[k]; total += wave_tot[k]; }
+    for (long g = g_lo; g < g_hi && pos < kPlanCap; ++g) {
+        unsigned long long m = marks[g];
+        while (m != 0ull && pos < kPlanCap) {
+            clist[pos++] = (int)(g * kGroup + __builtin_ctzll(m));
+            m &= m - 1ull;
+        }
+    }
+    __syncthreads();
+    const int n = total < kPlanCap ? total : kPlanCap;
+    if (blockIdx.x == 0) {
+        for (int k = t; k < n; k += 256) plist[k] = clist[k];
+        if (t == 0) *pn = n;
+    }
+    for (int k = blockIdx.x * 4 + wv; k <= n; k += gridDim.x * 4) {
+        double *ent = dump + (long)k * kEntry;
+        const long from = (k == 0) ? 0 : (long)clist[k - 1] + 1, to = (k < n) ? (long)clist[k] : nchunks;
+        const Summary st = stretch_summary(chunks, groups, supers, from, to, lane);
+        if (lane == 0) {
+            xv2 *ps = reinterpret_cast<xv2 *>(ent + kChunk + 64 * kPieceDoubles);
+            xv2 v0, v1;
+            v0.x = st.D; v0.y = st.mn; v1.x = st.mx; v1.y = __hiloint2double(st.bad & 1, st.e);
+            ps[0] = v0; ps[1] = v1;
+        }
+        if (k == n) break;
+        const long c = clist[k];
+        const long lo = c * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
+        double p[kPerLane];
+        src.chunk16(lo, hi, lane, T[wv], p);
+        xv2 *dst = reinterpret_cast<xv2 *>(ent + lane * kPerLane);
+#pragma unroll
+        for (int i = 0; i < kPerLane / 2; ++i) { xv2 v; v.x = p[2 * i]; v.y = p[2 * i + 1]; dst[i] = v; }
+        const int e_g = exponent_of(goff[c / kGroup] + approx[c]);
+        if (lane == 0) pexp[k] = e_g;
+        if (e_g != kNoExp) {
+            double out[kPieceDoubles];
+            int flags = 0;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const Summary q = piece_summary(p, e_g + h - 1);
+                out[3 * h] = q.D; out[3 * h + 1] = q.mn; out[3 * h + 2] = q.mx;
+                flags |= (q.bad & 1) << h;
+                if (q.e == kAnyExp) flags |= 8;
+            }
+            out[9] = __hiloint2double(0, flags);
+            xv2 *pd = reinterpret_cast<xv2 *>(ent + kChunk + lane * kPieceDoubles);
+#pragma unroll
+            for (int i = 0; i < kPieceDoubles / 2; ++i) { xv2 v; v.x = out[2 * i]; v.y = out[2 * i + 1]; pd[i] = v; }
+        }
+    }
+}
+
+// What the walk holds of one entry of the plan.
+struct Entry {
+    xv2 p[kPerLane / 2];                              // the chunk's products
+    xv2 q[kPieceDoubles / 2];                         // its prepared pieces
+    xv2 st[2];                                        // the stretch before it
+};
+
+// The hierarchical walk over the chunks [a, b), without a plan: group summaries 64 at a time where whole groups
+// lie ahead, the chunks of a group that does not apply (or is only partly inside the range), the elements of a
+// chunk that does not apply.  Everything it needs is fetched on the spot.
+template <class Src>
+__device__ __forceinline__ double walk_range(const Src &src, long count, const Summary *__restrict__ chunks,
+                                             long nchunks, const Summary *__restrict__ groups, long a, long b, double s,
+                                             int lane, double *T, long &n_groups, long &n_chunks, long *tally)
+{
+    long pos = a;
+    bool descend = false;
+    while (pos < b) {
+        if (!descend && pos % kGroup == 0 && pos + kGroup <= b) {
+            const long g0 = pos / kGroup, gw = b / kGroup - g0;
+            const int ng = (gw < 64) ? (int)gw : 64;
+            const Summary gmine = (lane < ng) ? groups[g0 + lane] : identity();
+            const int gf = walk(gmine, ng, 0, s, lane);
+            pos += (long)gf * kGroup;
+            if (gf < ng) { descend = true; ++n_groups; }
+        } else {
+            const long cb = (pos / kGroup) * kGroup;
+            const int from = (int)(pos - cb);
+            const long room = ((b < nchunks) ? b : nchunks) - cb;
+            const int nc = (room < 64) ? (int)room : 64;
+            const Summary cmine = (lane < nc) ? chunks[cb + lane] : identity();
+            const int cf = walk(cmine, nc, from, s, lane);
+            if (cf < nc) {
+                ++n_chunks;
+                const long lo = (cb + cf) * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
+                double p[kPerLane];
+                Pieces none;
+                none.flags = 0;
+                src.chunk16(lo, hi, lane, T, p);
+                s = refine(p, none, kNoExp, lo, hi, s, lane, tally);
+                pos = cb + cf + 1;
+            } else {
+                pos = cb + nc;
+            }
+            if (pos % kGroup == 0) descend = false;
+        }
+    }
+    return s;
+}
+
+// The ordered walk, one wavefront -- so nothing hides a wait, and everything it will need is laid out for it
+// beforehand by the plan (plist / pexp / pn / dump; plist may be null: then the whole range is walked
+// hierarchically).  Per entry of the plan: the stretch of chunks before the entry's chunk is applied in one step if
+// its summary holds for the true accumulator (walked hierarchically otherwise), then the chunk is taken apart
+// with its staged products and prepared pieces (taking apart a chunk that would have applied after all costs one
+// scan of its pieces and is as exact as everything else).  The next two entries are always on their way.
+// stats (may be null): [0] stretches walked hierarchically plus groups descended into, [1] chunks taken apart,
+// [2] rounds of piece summaries inside them, [3] pieces replayed without summarising, [4] chunks taken apart
+// according to the plan.
 template <class Src>
 __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                                                 const Summary *__restrict__ chunks, long nchunks,
                                                 const Summary *__restrict__ groups, long ngroups, double start,
-                                                const double *start_dev, double *result, long *stats)
+                                                const double *start_dev, double *result, long *stats,
+                                                const int *__restrict__ plist, const int *__restrict__ pexp,
+                                                const int *__restrict__ pn, const double *__restrict__ dump)
 {
     __shared__ __attribute__((aligned(16))) double T[Src::kLds];
+    __shared__ int lst[kPlanCap], lexp[kPlanCap];
     Src src = src_in;
     src.prepare();
     const int lane = threadIdx.x;
     double s = (start_dev != nullptr) ? *start_dev : start;
-    long n_groups = 0, n_chunks = 0, tally[2] = {0, 0};
-    Summary nxt = (lane < ngroups) ? groups[lane] : identity();
-    for (long gb = 0; gb < ngroups; gb += 64) {
-        const int ng = (ngroups - gb < 64) ? (int)(ngroups - gb) : 64;
-        const Summary gmine = nxt;
-        if (gb + 64 + lane < ngroups) nxt = groups[gb + 64 + lane];
-        int gpos = 0;
-        while (gpos < ng) {
-            const int gf = walk(gmine, ng, gpos, s, lane);
-            if (gf >= ng) break;
-            // group gb+gf does not apply as a whole: walk its chunks
-            ++n_groups;
-            const long cb = (gb + gf) * kGroup;
-            const int nc = (nchunks - cb < 64) ? (int)(nchunks - cb) : 64;
-            const Summary cmine = (lane < nc) ? chunks[cb + lane] : identity();
-            int cpos = 0;
-            while (cpos < nc) {
-                const int cf = walk(cmine, nc, cpos, s, lane);
-                if (cf >= nc) break;
-                ++n_chunks;
-                const long lo = (cb + cf) * kChunk;
-                const long hi = (lo + kChunk < count) ? lo + kChunk : count;
-                s = refine(src, lo, hi, s, lane, T, tally);
-                cpos = cf + 1;
+    long n_groups = 0, n_chunks = 0, n_planned = 0, tally[2] = {0, 0};
+#ifdef CG_WALK_CLOCKS
+    long clk_ref = 0, clk_st = 0, clk_all = clock64();
+#endif
+    if (plist == nullptr) {
+        s = walk_range(src, count, chunks, nchunks, groups, 0, nchunks, s, lane, T, n_groups, n_chunks, tally);
+    } else {
+        int n = *pn;
+        if (n > kPlanCap) n = kPlanCap;
+        for (int k = lane; k < n; k += 64) { lst[k] = plist[k]; lexp[k] = pexp[k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Entry ent[2];                                  // entries k and k + 1
+        auto fetch_entry = [&](int k, Entry &e) {      // loads only; nothing waits for them here
+            if (k > n) return;
+            const double *base = dump + (long)k * kEntry;
+            const xv2 *fs = reinterpret_cast<const xv2 *>(base + kChunk + 64 * kPieceDoubles);
+            e.st[0] = fs[0]; e.st[1] = fs[1];
+            if (k == n) return;
+            const xv2 *from = reinterpret_cast<const xv2 *>(base + lane * kPerLane);
+#pragma unroll
+            for (int i = 0; i < kPerLane / 2; ++i) e.p[i] = from[i];
+            const xv2 *fq = reinterpret_cast<const xv2 *>(base + kChunk + lane * kPieceDoubles);
+#pragma unroll
+            for (int i = 0; i < kPieceDoubles / 2; ++i) e.q[i] = fq[i];
+        };
+        fetch_entry(0, ent[0]);
+        fetch_entry(1, ent[1]);
+        long pos = 0;
+        for (int k = 0; k <= n; ++k) {
+            const Entry cur = ent[0];
+            ent[0] = ent[1];
+            fetch_entry(k + 2, ent[1]);
+            const long end = (k < n) ? (long)lst[k] : nchunks;
+            if (pos < end) {
+#ifdef CG_WALK_CLOCKS
+                const long t_s = clock64();
+#endif
+                Summary st;
+                st.D = cur.st[0].x; st.mn = cur.st[0].y; st.mx = cur.st[1].x;
+                st.e = __double2loint(cur.st[1].y); st.bad = __double2hiint(cur.st[1].y);
+                const int es = exponent_of(s);
+                const double S = (es == kNoExp) ? 0.0 : ldexp(s, 52 - es);
+                if (holds(st, es, S, (s == 0.0) && signbit(s))) {
+                    if (st.e != kAnyExp) s = ldexp(S + st.D, es - 52);      // exact: integers below 2^53
+                } else {
+                    ++n_groups;
+                    s = walk_range(src, count, chunks, nchunks, groups, pos, end, s, lane, T, n_groups, n_chunks, tally);
+                }
+#ifdef CG_WALK_CLOCKS
+                clk_st += clock64() - t_s;
+#endif
             }
-            gpos = gf + 1;
+            if (k < n) {
+                const long lo = end * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
+                double p[kPerLane];
+                Pieces pre;
+#pragma unroll
+                for (int i = 0; i < kPerLane / 2; ++i) { p[2 * i] = cur.p[i].x; p[2 * i + 1] = cur.p[i].y; }
+                const xv2 *q = cur.q;
+                pre.D[0] = q[0].x; pre.mn[0] = q[0].y; pre.mx[0] = q[1].x;
+                pre.D[1] = q[1].y; pre.mn[1] = q[2].x; pre.mx[1] = q[2].y;
+                pre.D[2] = q[3].x; pre.mn[2] = q[3].y; pre.mx[2] = q[4].x;
+                pre.flags = __double2loint(q[4].y);
+                ++n_chunks; ++n_planned;
+#ifdef CG_WALK_CLOCKS
+                const long t_r = clock64();
+#endif
+                s = refine(p, pre, lexp[k], lo, hi, s, lane, tally);
+#ifdef CG_WALK_CLOCKS
+                clk_ref += clock64() - t_r;
+#endif
+                pos = end + 1;
+            }
         }
     }
     if (lane == 0) {
         *result = s;
-        if (stats != nullptr) { stats[0] = n_groups; stats[1] = n_chunks; stats[2] = tally[0]; stats[3] = tally[1]; }
+        if (stats != nullptr) {
+            stats[0] = n_groups; stats[1] = n_chunks; stats[2] = tally[0]; stats[3] = tally[1]; stats[4] = n_planned;
+#ifdef CG_WALK_CLOCKS
+            stats[5] = clock64() - clk_all; stats[6] = clk_st; stats[7] = clk_ref;
+#endif
+        }
     }
 }
 
@@ -761,8 +1051,11 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
 struct Workspace {
     double *approx = nullptr, *goff = nullptr;
     double *sub = nullptr;                // span sums handed over by the producing kernel (kSub products each)
-    Summary *chunks = nullptr, *groups = nullptr;
-    long *stats = nullptr;                // what the last walks did: [4*which + 0..3] groups, chunks, rounds, blind pieces
+    Summary *chunks = nullptr, *groups = nullptr, *supers = nullptr;   // three levels of summaries: 1024, 64 x 1024, 64 x 64 x 1024 products
+    long *stats = nullptr;                // what the last walks did: [8*which + 0..4], see k_xs_walk
+    unsigned long long *marks = nullptr;  // per group: the chunks the walk is expected to take apart
+    int *plist = nullptr, *pexp = nullptr, *pn = nullptr;  // the plan: those chunks in order, their predicted binades, how many
+    double *dump = nullptr;               // their products and prepared pieces (kEntry doubles each)
     long cap_chunks = 0;
     // speculative path (reserve_spec): span sums under two hypotheses, the hypotheses of the two dot products of
     // an iteration (they persist from one iteration to the next), the repair list
@@ -786,6 +1079,13 @@ struct Workspace {
         if ((e = hipMalloc(&goff, (size_t)ng * sizeof(double))) != hipSuccess) return e;
         if ((e = hipMalloc(&chunks, (size_t)nc * sizeof(Summary))) != hipSuccess) return e;
         if ((e = hipMalloc(&groups, (size_t)ng * sizeof(Summary))) != hipSuccess) return e;
+        if ((e = hipMalloc(&supers, (size_t)((ng + kGroup - 1) / kGroup) * sizeof(Summary))) != hipSuccess) return e;
+        if ((e = hipMalloc(&marks, (size_t)ng * sizeof(unsigned long long))) != hipSuccess) return e;
+        if ((e = hipMalloc(&plist, (size_t)kPlanCap * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMalloc(&pexp, (size_t)kPlanCap * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMalloc(&pn, 256)) != hipSuccess) return e;
+        if ((e = hipMemset(pn, 0, 256)) != hipSuccess) return e;
+        if ((e = hipMalloc(&dump, (size_t)(kPlanCap + 1) * kEntry * sizeof(double))) != hipSuccess) return e;
         cap_chunks = nc;
         return hipSuccess;
     }
@@ -828,9 +1128,11 @@ struct Workspace {
     void release()
     {
         release_spec();
-        (void)hipFree(approx); (void)hipFree(goff); (void)hipFree(chunks); (void)hipFree(groups);
-        (void)hipFree(sub); (void)hipFree(stats);
-        approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; sub = nullptr; stats = nullptr;
+        (void)hipFree(approx); (void)hipFree(goff); (void)hipFree(chunks); (void)hipFree(groups); (void)hipFree(supers);
+        (void)hipFree(sub); (void)hipFree(stats); (void)hipFree(marks); (void)hipFree(plist); (void)hipFree(pexp); (void)hipFree(pn);
+        (void)hipFree(dump);
+        approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; supers = nullptr; sub = nullptr; stats = nullptr;
+        marks = nullptr; plist = nullptr; pexp = nullptr; pn = nullptr; dump = nullptr;
         cap_chunks = 0;
     }
 };
@@ -851,7 +1153,8 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
     const SrcArrays src{v, w, count > 0 ? count : 0, vec};
     if (count <= 0) {
         hipLaunchKernelGGL(k_xs_walk<SrcArrays>, dim3(1), dim3(64), 0, s, src, 0L, ws.chunks, 0L, ws.groups, 0L,
-                           start, start_dev, result, (long *)nullptr);
+                           start, start_dev, result, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
+                           (const int *)nullptr, (const double *)nullptr);
         return;
     }
     const long nc = Workspace::chunks_for(count);
@@ -869,9 +1172,14 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
         hipLaunchKernelGGL(k_xs_chunk<true>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     else
         hipLaunchKernelGGL(k_xs_chunk<false>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
-    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
+    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
+    const long nsup = (ng + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((nsup + 3) / 4)), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup,
+                       (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_xs_plan<SrcArrays>, dim3(kPlanBlocks), dim3(256), 0, s, src, count, ws.chunks, nc, ws.groups, ws.supers,
+                       ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump);
     hipLaunchKernelGGL(k_xs_walk<SrcArrays>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, start_dev, result, ws.stats);
+                       start, start_dev, result, ws.stats, ws.plist, ws.pexp, ws.pn, ws.dump);
 }
 
 // The same result from the speculative span sums the producing kernel left in the workspace (sub, spD*, spQ*
@@ -894,9 +1202,14 @@ inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, lon
     hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, ws.sub, ws.spD0,
                        nonneg ? (const double *)nullptr : ws.spQ0, ws.spD1, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
     hipLaunchKernelGGL(k_sp_fix<Src>, dim3(1024), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
-    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng);
+    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
+    const long nsup = (ng + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((nsup + 3) / 4)), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup,
+                       (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_xs_plan<Src>, dim3(kPlanBlocks), dim3(256), 0, s, src, count, ws.chunks, nc, ws.groups, ws.supers,
+                       ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump);
     hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, (const double *)nullptr, result, ws.stats + 4 * which);
+                       start, (const double *)nullptr, result, ws.stats + 8 * which, ws.plist, ws.pexp, ws.pn, ws.dump);
 }
 
 } // namespace exact
