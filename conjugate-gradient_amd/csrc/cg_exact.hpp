@@ -106,11 +106,12 @@ __device__ __forceinline__ Summary wave_compose(Summary cur)
     return cur;
 }
 
-// Exponent of a finite non-zero normal double, else kNoExp.
+// Exponent of a finite double of magnitude at least 2^-1021, else kNoExp (zero, subnormal, the lowest normal
+// binade, infinities, NaNs): the biased exponent field, 2 .. 0x7fe.
 __device__ __forceinline__ int exponent_of(double s)
 {
-    if (!(fabs(s) >= 0x1p-1021) || !(fabs(s) <= 0x1.fffffffffffffp+1023)) return kNoExp;
-    return ilogb(s);
+    const int be = (__double2hiint(s) >> 20) & 0x7ff;
+    return (be >= 2 && be <= 0x7fe) ? be - 1023 : kNoExp;
 }
 
 // Summary of kPerLane consecutive addends under the hypothesis "exponent e".
@@ -710,56 +711,105 @@ __device__ __forceinline__ int walk(const Summary &mine, int n, int from, double
 }
 #undef CG_SCAN_STEP
 
-// Piece summaries of a staged chunk under the three binades around the one its approximate prefix sum predicts
-// (e_g - 1, e_g, e_g + 1), as the plan prepares them: what refine would otherwise compute on the spot, twice per
-// chunk as a rule (the binade the accumulator arrives in, and the one it leaves in).
+// The pieces of a staged chunk (16 consecutive products per lane) under the three binades around the one its
+// approximate prefix sum predicts (h = 0, 1, 2: e_g - 1, e_g, e_g + 1), as the plan prepares them, in PREFIX form:
+// P = the sum of the pieces' D up to and including this lane's, lo / hi = the extremes of the running value inside
+// this lane's piece counted from the chunk's start (the sum before the piece plus its mn / mx).  A run of pieces
+// from piece `from` on then needs no scan at all: with base = P of piece from-1, piece l applies iff
+// S + (lo - base) and S + (hi - base) stay inside the binade, a test every lane makes for itself.  A piece that
+// cannot be summarised (a tie, a NaN, a huge addend) counts 0 in P and carries its flag: the walk replays it
+// literally and goes on behind it with base = its P.  The plan vouches for a hypothesis (bit 4+h clear) only if
+// every P, lo, hi stays below 2^51 in magnitude, so that all these differences are exact.
 struct Pieces {
-    double D[3], mn[3], mx[3];
-    int flags;                                        // bit h: unusable under hypothesis h; bit 3: the piece holds zeros only
+    double P0, lo0, hi0, P1, lo1, hi1, P2, lo2, hi2;
+    int flags;                                        // bit h: this piece is unusable under hypothesis h; bit 4+h: hypothesis h is not prepared
 };
-constexpr int kPieceDoubles = 10;                     // per lane: 3 x (D, mn, mx) and the flags
+constexpr int kPieceDoubles = 10;                     // per lane: 3 x (P, lo, hi) and the flags
 constexpr int kEntry = kChunk + 64 * kPieceDoubles + 4;   // doubles per entry of the plan: products, pieces, a stretch summary
 
-__device__ __forceinline__ Summary piece_of(const Pieces &q, int h, int e)
+__device__ __forceinline__ double read_lane(double v, int l)        // l wave-uniform
 {
-    Summary m;
-    if (q.flags & 8) return identity();
-    m.D = (h == 0) ? q.D[0] : (h == 1) ? q.D[1] : q.D[2];
-    m.mn = (h == 0) ? q.mn[0] : (h == 1) ? q.mn[1] : q.mn[2];
-    m.mx = (h == 0) ? q.mx[0] : (h == 1) ? q.mx[1] : q.mx[2];
-    m.e = e;
-    m.bad = (q.flags >> h) & 1;
-    return m;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// A chunk whose stored summary does not apply, its products p held as 16 consecutive elements per lane (one
-// piece each): summarise the pieces under the accumulator's ACTUAL exponent (or take the prepared summaries when
-// that exponent is one of the three around e_g; e_g = kNoExp: nothing prepared), apply the longest valid run,
-// replay the one offending piece literally, and repeat with the new exponent.
-__device__ __forceinline__ double refine(const double (&p)[kPerLane], const Pieces &pre, int e_g, long lo, long hi,
-                                         double s, int lane, long *tally)
+// A value every lane holds alike, moved to a scalar register: the compiler cannot know that it is uniform, and
+// would otherwise steer the walk's control flow with lane masks and select operands through memory.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long uniform(long v)
 {
-    int piece = 0;
+    return ((long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// Piece f of a chunk (the 16 products lane f holds) added one by one, as the reference adds them.
+__device__ __forceinline__ double replay_piece(const double (&p)[kPerLane], int f, long first, long hi, double s)
+{
+    if (first + kPerLane <= hi) {                     // wave-uniform
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) s += read_lane(p[i], f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const double pi = read_lane(p[i], f);
+            if (first + i < hi) s += pi;
+        }
+    }
+    return s;
+}
+
+// A chunk that is to be taken apart, its products p held as 16 consecutive elements per lane (one piece each),
+// from piece `piece` on: summarise the pieces under the accumulator's ACTUAL exponent, apply the longest valid run,
+// replay the one offending piece literally, and repeat with the new exponent.
+__device__ __forceinline__ double refine_from(const double (&p)[kPerLane], int piece, long lo, long hi, double s, int lane,
+                                              long *tally)
+{
     for (int round = 0; piece < 64; ++round) {
         int f = piece;                               // after many crossings or ties: stop summarising, one piece at a time
         if (round < 24) {
-            const int es = exponent_of(s);
-            const int h = es - e_g + 1;
-            Summary mine;
-            if (e_g != kNoExp && es != kNoExp && h >= 0 && h <= 2) mine = piece_of(pre, h, es);    // wave-uniform
-            else mine = piece_summary(p, es);
-            f = walk(mine, 64, piece, s, lane);
+            const Summary mine = piece_summary(p, exponent_of(s));
+            f = uniform(walk(mine, 64, piece, s, lane));
             if (f >= 64) break;
             ++tally[0];
         } else {
             ++tally[1];
         }
-        const long first = lo + (long)f * kPerLane;
-#pragma unroll
-        for (int i = 0; i < kPerLane; ++i) {         // the offending piece, literally, from the registers of lane f
-            const double pi = __shfl(p[i], f, 64);
-            if (first + i < hi) s += pi;
-        }
+        s = replay_piece(p, f, lo + (long)f * kPerLane, hi, s);
+        piece = f + 1;
+    }
+    return s;
+}
+
+// The same with the plan's prepared pieces: as long as the accumulator's exponent is one of the three the plan
+// vouches for, a run of pieces costs one test per lane and a ballot; otherwise the rest of the chunk goes the
+// general way.  e_g, lo, hi wave-uniform (scalar).
+__device__ __forceinline__ double refine(const double (&p)[kPerLane], const Pieces &pre, int e_g, long lo, long hi,
+                                         double s, int lane, long *tally)
+{
+    int piece = 0;
+    const int prepared = uniform(pre.flags >> 4);     // the same in every lane
+    // nine separate registers from here on (the compiler would otherwise pick the hypothesis by ADDRESS and read
+    // it back from scratch memory, in the middle of the walk's critical path)
+    double P0 = pre.P0, lo0 = pre.lo0, hi0 = pre.hi0, P1 = pre.P1, lo1 = pre.lo1, hi1 = pre.hi1, P2 = pre.P2, lo2 = pre.lo2,
+           hi2 = pre.hi2;
+    asm volatile("" : "+v"(P0), "+v"(lo0), "+v"(hi0), "+v"(P1), "+v"(lo1), "+v"(hi1), "+v"(P2), "+v"(lo2), "+v"(hi2));
+    while (piece < 64) {
+        const int es = uniform(exponent_of(s));
+        const int h = es - e_g + 1;
+        if (e_g == kNoExp || es == kNoExp || h < 0 || h > 2 || ((prepared >> h) & 1))
+            return refine_from(p, piece, lo, hi, s, lane, tally);
+        const double S = ldexp(s, 52 - es);
+        const double P = (h == 0) ? P0 : (h == 1) ? P1 : P2;
+        const double plo = (h == 0) ? lo0 : (h == 1) ? lo1 : lo2;
+        const double phi = (h == 0) ? hi0 : (h == 1) ? hi1 : hi2;
+        const double base = (piece > 0) ? read_lane(P, piece - 1) : 0.0;
+        const double a = S + (plo - base), b = S + (phi - base);
+        bool ok = (S > 0.0) ? (a >= 0x1p52 + 1.0) && (b <= 0x1p53 - 1.0) : (b <= -(0x1p52 + 1.0)) && (a >= -(0x1p53 - 1.0));
+        ok = ok && !((pre.flags >> h) & 1);
+        const unsigned long long failed = ~__ballot(ok) & ~((1ull << piece) - 1ull);
+        const int f = failed ? (int)__builtin_ctzll(failed) : 64;
+        if (f > piece) s = ldexp(S + (read_lane(P, f - 1) - base), es - 52);     // exact: integers below 2^53
+        if (f >= 64) break;
+        ++tally[0];
+        s = replay_piece(p, f, lo + (long)f * kPerLane, hi, s);
         piece = f + 1;
     }
     return s;
@@ -874,9 +924,20 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
                 const Summary q = piece_summary(p, e_g + h - 1);
-                out[3 * h] = q.D; out[3 * h + 1] = q.mn; out[3 * h + 2] = q.mx;
-                flags |= (q.bad & 1) << h;
-                if (q.e == kAnyExp) flags |= 8;
+                const bool bad = (q.bad & 1) != 0;
+                const double D = bad ? 0.0 : q.D;
+                double P = D;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double up = __shfl_up(P, off, 64);
+                    if (lane >= off) P += up;
+                }
+                const double E = P - D;
+                const double plo = bad ? E : E + q.mn, phi = bad ? E : E + q.mx;
+                const bool big = !(fabs(P) < 0x1p51) || !(fabs(plo) < 0x1p51) || !(fabs(phi) < 0x1p51);
+                out[3 * h] = P; out[3 * h + 1] = plo; out[3 * h + 2] = phi;
+                if (bad) flags |= 1 << h;
+                if (__ballot(big) != 0ull) flags |= 16 << h;
             }
             out[9] = __hiloint2double(0, flags);
             xv2 *pd = reinterpret_cast<xv2 *>(ent + kChunk + lane * kPieceDoubles);
@@ -922,10 +983,8 @@ __device__ __forceinline__ double walk_range(const Src &src, long count, const S
                 ++n_chunks;
                 const long lo = (cb + cf) * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
                 double p[kPerLane];
-                Pieces none;
-                none.flags = 0;
                 src.chunk16(lo, hi, lane, T, p);
-                s = refine(p, none, kNoExp, lo, hi, s, lane, tally);
+                s = refine_from(p, 0, lo, hi, s, lane, tally);
                 pos = cb + cf + 1;
             } else {
                 pos = cb + nc;
@@ -966,13 +1025,13 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
     if (plist == nullptr) {
         s = walk_range(src, count, chunks, nchunks, groups, 0, nchunks, s, lane, T, n_groups, n_chunks, tally);
     } else {
-        int n = *pn;
+        int n = uniform(*pn);
         if (n > kPlanCap) n = kPlanCap;
         for (int k = lane; k < n; k += 64) { lst[k] = plist[k]; lexp[k] = pexp[k]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        Entry ent[2];                                  // entries k and k + 1
+        Entry ent[2];                                  // entries k and k + 1, alternating (no copies: the loop runs in pairs)
         auto fetch_entry = [&](int k, Entry &e) {      // loads only; nothing waits for them here
             if (k > n) return;
             const double *base = dump + (long)k * kEntry;
@@ -986,14 +1045,9 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
 #pragma unroll
             for (int i = 0; i < kPieceDoubles / 2; ++i) e.q[i] = fq[i];
         };
-        fetch_entry(0, ent[0]);
-        fetch_entry(1, ent[1]);
         long pos = 0;
-        for (int k = 0; k <= n; ++k) {
-            const Entry cur = ent[0];
-            ent[0] = ent[1];
-            fetch_entry(k + 2, ent[1]);
-            const long end = (k < n) ? (long)lst[k] : nchunks;
+        auto step = [&](int k, Entry &cur) {           // entry k: the stretch before its chunk, then the chunk
+            const long end = (k < n) ? (long)uniform(lst[k]) : nchunks;
             if (pos < end) {
 #ifdef CG_WALK_CLOCKS
                 const long t_s = clock64();
@@ -1020,19 +1074,29 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
 #pragma unroll
                 for (int i = 0; i < kPerLane / 2; ++i) { p[2 * i] = cur.p[i].x; p[2 * i + 1] = cur.p[i].y; }
                 const xv2 *q = cur.q;
-                pre.D[0] = q[0].x; pre.mn[0] = q[0].y; pre.mx[0] = q[1].x;
-                pre.D[1] = q[1].y; pre.mn[1] = q[2].x; pre.mx[1] = q[2].y;
-                pre.D[2] = q[3].x; pre.mn[2] = q[3].y; pre.mx[2] = q[4].x;
+                pre.P0 = q[0].x; pre.lo0 = q[0].y; pre.hi0 = q[1].x;
+                pre.P1 = q[1].y; pre.lo1 = q[2].x; pre.hi1 = q[2].y;
+                pre.P2 = q[3].x; pre.lo2 = q[3].y; pre.hi2 = q[4].x;
                 pre.flags = __double2loint(q[4].y);
                 ++n_chunks; ++n_planned;
 #ifdef CG_WALK_CLOCKS
                 const long t_r = clock64();
 #endif
-                s = refine(p, pre, lexp[k], lo, hi, s, lane, tally);
+                s = refine(p, pre, uniform(lexp[k]), lo, hi, s, lane, tally);
 #ifdef CG_WALK_CLOCKS
                 clk_ref += clock64() - t_r;
 #endif
                 pos = end + 1;
+            }
+        };
+        fetch_entry(0, ent[0]);
+        fetch_entry(1, ent[1]);
+        for (int k = 0; k <= n; k += 2) {
+            step(k, ent[0]);
+            fetch_entry(k + 2, ent[0]);
+            if (k + 1 <= n) {
+                step(k + 1, ent[1]);
+                fetch_entry(k + 3, ent[1]);
             }
         }
     }
@@ -1046,6 +1110,45 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
         }
     }
 }
+
+#ifdef CG_DEBUG_XS
+// Diagnostic build only: the same dot product by the literal recurrence, and a comparison that reports.
+template <class Src>
+__global__ __launch_bounds__(64) void k_xs_literal(const Src src_in, long count, double start, double *result)
+{
+    Src src = src_in;
+    src.prepare();
+    const double s = replay(src, 0, count, start, (int)threadIdx.x);
+    if (threadIdx.x == 0) *result = s;
+}
+// Every usable chunk summary against one recomputed from the products under the same hypothesis.
+template <class Src>
+__global__ __launch_bounds__(256) void k_xs_audit(const Src src_in, long count, const Summary *__restrict__ chunks, long nchunks,
+                                                  int which)
+{
+    __shared__ __attribute__((aligned(16))) double T[4][Src::kLds];
+    Src src = src_in;
+    src.prepare();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (long c = (long)blockIdx.x * 4 + wv; c < nchunks; c += (long)gridDim.x * 4) {
+        const Summary st = chunks[c];
+        if ((st.bad & 1) || st.e == kAnyExp) continue;
+        const long lo = c * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
+        double p[kPerLane];
+        src.chunk16(lo, hi, lane, T[wv], p);
+        Summary t = wave_compose_same_e(piece_summary(p, st.e), st.e);
+        t.D = __shfl(t.D, 0, 64); t.mn = __shfl(t.mn, 0, 64); t.mx = __shfl(t.mx, 0, 64); t.bad = __shfl(t.bad, 0, 64);
+        if (lane == 0 && (t.bad || t.D != st.D || t.mn < st.mn || t.mx > st.mx))
+            printf("dot %d chunk %ld e %d: stored D %a mn %a mx %a | true D %a mn %a mx %a bad %d\n", which, c, st.e, st.D, st.mn,
+                   st.mx, t.D, t.mn, t.mx, t.bad);
+    }
+}
+__global__ void k_xs_compare(const double *plan, const double *hier, const double *lit, int which)
+{
+    if (*plan != *lit || *hier != *lit)
+        printf("strict dot %d: plan %a hierarchical %a literal %a\n", which, *plan, *hier, *lit);
+}
+#endif
 
 // Workspace for `count` elements.
 struct Workspace {
@@ -1210,6 +1313,15 @@ inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, lon
                        ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump);
     hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
                        start, (const double *)nullptr, result, ws.stats + 8 * which, ws.plist, ws.pexp, ws.pn, ws.dump);
+#ifdef CG_DEBUG_XS
+    double *dbg = reinterpret_cast<double *>(ws.stats + 24);
+    hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
+                       start, (const double *)nullptr, dbg, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
+                       (const int *)nullptr, (const double *)nullptr);
+    hipLaunchKernelGGL(k_xs_audit<Src>, dim3(256), dim3(256), 0, s, src, count, ws.chunks, nc, which);
+    hipLaunchKernelGGL(k_xs_literal<Src>, dim3(1), dim3(64), 0, s, src, count, start, dbg + 1);
+    hipLaunchKernelGGL(k_xs_compare, dim3(1), dim3(1), 0, s, result, dbg, dbg + 1, which);
+#endif
 }
 
 } // namespace exact

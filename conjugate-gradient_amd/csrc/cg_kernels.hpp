@@ -314,6 +314,20 @@ template <> struct BufIO<2> {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), r, off, 0, kAuxNT);
     }
 };
+// The same with a scalar byte offset on top (one descriptor for a whole tile, the row picked by the scalar part).
+__device__ __forceinline__ void buf_load2s(__amdgpu_buffer_rsrc_t r, int off, int soff, double (&v)[2])
+{
+    const v2d t = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, kAuxNT));
+    v[0] = t.x; v[1] = t.y;
+}
+__device__ __forceinline__ void buf_load2s(__amdgpu_buffer_rsrc_t r, int off, int soff, double (&v)[1])
+{
+    v[0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, kAuxNT));
+}
+__device__ __forceinline__ double buf_load1s(__amdgpu_buffer_rsrc_t r, int off, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+}
 __device__ __forceinline__ double buf_load1(__amdgpu_buffer_rsrc_t r, int off)
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
@@ -372,10 +386,10 @@ struct SpanEntry {
     int pad;
 };
 #ifndef CG_SPAN_LDS_MIN_MODE
-#define CG_SPAN_LDS_MIN_MODE 4
+#define CG_SPAN_LDS_MIN_MODE 99
 #endif
 #ifndef CG_SPAN_GROUPED
-#define CG_SPAN_GROUPED 0
+#define CG_SPAN_GROUPED 1
 #endif
 #ifndef CG_SPAN_ROWS
 #define CG_SPAN_ROWS 8
@@ -468,6 +482,161 @@ __device__ __forceinline__ void span_flush(const SpanEntry *red, long mb, long m
     }
 }
 
+// ---- eight rows at once -----------------------------------------------------------------------------------
+// The read-only pass holds the entries of eight consecutive rows in registers, and eight sums over the wavefront
+// need not cost eight reductions: halves of the wavefront trade rows (each keeps four rows and receives the other
+// half's contributions to them), then quarters, then eighths, and what is left is one sum over eight lanes --
+// v[p] of lane l ends up, summed over all lanes, in the eight lanes 8p .. 8p+7.  34 instructions per quantity
+// for the eight rows, against 8 x 18 when each row is reduced by itself.
+__device__ __forceinline__ void swap_add32(double &a, double b)     // a <- [a.lower + a.upper | b.lower + b.upper]  (halves of 32 lanes)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap_add16(double &a, double b)     // rows of 16 lanes: a <- [a0 + a1 | b0 + b1 | a2 + a3 | b2 + b3]
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_move(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+}
+// v[p], p = 0..7, summed over the wavefront (in no particular order); the sum of v[p] is returned in lanes 8p .. 8p+7.
+__device__ __forceinline__ double wave_sum8(double (&v)[8])
+{
+    const bool upper = (threadIdx.x & 8) != 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) swap_add32(v[p], v[p + 4]);          // lanes 0..31: rows 0..3, lanes 32..63: rows 4..7
+    swap_add16(v[0], v[2]);                                          // rows of 16 lanes now hold rows 0, 2, 4, 6 ...
+    swap_add16(v[1], v[3]);                                          // ... and 1, 3, 5, 7
+    const double keep = upper ? v[1] : v[0], give = upper ? v[0] : v[1];
+    double y = keep + dpp_move<0x128>(give);                              // row_ror:8 -- eight lanes per row
+    y += dpp_move<0xB1>(y);                                          // quad_perm [1,0,3,2]
+    y += dpp_move<0x4E>(y);                                          // quad_perm [2,3,0,1]
+    y += dpp_move<0x141>(y);                                         // row_half_mirror: the other quad of the eight
+    return y;
+}
+
+// The same tree taken as the rows arrive, so that at most three partly reduced quadruples are alive at a time
+// (entries of rows 2i and 2i+1 trade halves as soon as the second exists, pairs of those trade quarters, ...):
+// what a wavefront contributes to the four span arrays for one row, and its partial reductions.
+struct SpanQuad {
+    double su, d0, d1, q;
+};
+template <bool NONNEG>
+__device__ __forceinline__ SpanQuad quad_swap32(SpanQuad a, const SpanQuad &b)
+{
+    swap_add32(a.su, b.su); swap_add32(a.d0, b.d0); swap_add32(a.d1, b.d1);
+    if (!NONNEG) swap_add32(a.q, b.q);
+    return a;
+}
+template <bool NONNEG>
+__device__ __forceinline__ SpanQuad quad_swap16(SpanQuad a, const SpanQuad &b)
+{
+    swap_add16(a.su, b.su); swap_add16(a.d0, b.d0); swap_add16(a.d1, b.d1);
+    if (!NONNEG) swap_add16(a.q, b.q);
+    return a;
+}
+__device__ __forceinline__ double eight_finish(double x0, double x1)
+{
+    const bool upper = (threadIdx.x & 8) != 0;
+    const double keep = upper ? x1 : x0, give = upper ? x0 : x1;
+    double y = keep + dpp_move<0x128>(give);
+    y += dpp_move<0xB1>(y);
+    y += dpp_move<0x4E>(y);
+    y += dpp_move<0x141>(y);
+    return y;
+}
+struct Span8 {
+    SpanQuad pend, wpend, xpend;
+};
+// Row number P (0..7, a constant once the row loop is unrolled) of a batch of eight that begins at row m0: a
+// row with a half-way case gets a NaN for that hypothesis' D (planted in the lane that saw it, it travels through
+// the sums).  After row 7 the eight lanes 8k .. 8k+7 hold the sums of row bitrev3(k), and lane 8k stores them (rows
+// in [m_lo, m_hi) only).
+template <bool NONNEG>
+__device__ __forceinline__ void span8_push(Span8 &st, int P, const SpanEntry &e, bool t0, bool t1, long m0, long m_lo, long m_hi,
+                                           long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
+{
+    SpanQuad cur;
+    cur.su = e.sub;
+    cur.d0 = t0 ? __builtin_nan("") : e.D0;
+    cur.d1 = t1 ? __builtin_nan("") : e.D1;
+    cur.q = NONNEG ? 0.0 : (double)e.qf;
+    if ((P & 1) == 0) {
+        st.pend = cur;
+    } else {
+        const SpanQuad w = quad_swap32<NONNEG>(st.pend, cur);
+        if ((P & 2) == 0) {
+            st.wpend = w;
+        } else {
+            const SpanQuad x = quad_swap16<NONNEG>(st.wpend, w);
+            if ((P & 4) == 0) {
+                st.xpend = x;
+            } else {
+                const double rs = eight_finish(st.xpend.su, x.su), r0 = eight_finish(st.xpend.d0, x.d0),
+                             r1 = eight_finish(st.xpend.d1, x.d1);
+                double rq = 0.0;
+                if (!NONNEG) rq = eight_finish(st.xpend.q, x.q);
+                const int lane = threadIdx.x & 63, k = lane >> 3;
+                const long m = m0 + (((k & 1) << 2) | (k & 2) | (k >> 2));
+                if ((lane & 7) == 0 && m >= m_lo && m < m_hi) {
+                    sub[span_col + m] = rs;
+                    spD0[span_col + m] = r0;
+                    spD1[span_col + m] = r1;
+                    if (!NONNEG) spQ0[span_col + m] = rq * (1.0 + 0x1p-12) + 1.0;
+                }
+            }
+        }
+    }
+}
+
+// The same for batches of four rows (a kernel that keeps four rows of loads in flight): halves, then quarters, and
+// a sum over sixteen lanes; the sixteen lanes 16k .. 16k+15 end up with row [0, 2, 1, 3][k], lane 16k stores.
+__device__ __forceinline__ double four_finish(double y)
+{
+    y += dpp_move<0xB1>(y);                                          // quad_perm [1,0,3,2]
+    y += dpp_move<0x4E>(y);                                          // quad_perm [2,3,0,1]
+    y += dpp_move<0x141>(y);                                         // row_half_mirror
+    y += dpp_move<0x140>(y);                                         // row_mirror
+    return y;
+}
+template <bool NONNEG>
+__device__ __forceinline__ void span4_push(Span8 &st, int P, const SpanEntry &e, bool t0, bool t1, long m0, long m_lo, long m_hi,
+                                           long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
+{
+    SpanQuad cur;
+    cur.su = e.sub;
+    cur.d0 = t0 ? __builtin_nan("") : e.D0;
+    cur.d1 = t1 ? __builtin_nan("") : e.D1;
+    cur.q = NONNEG ? 0.0 : (double)e.qf;
+    if ((P & 1) == 0) {
+        st.pend = cur;
+    } else {
+        const SpanQuad w = quad_swap32<NONNEG>(st.pend, cur);
+        if ((P & 2) == 0) {
+            st.wpend = w;
+        } else {
+            const SpanQuad x = quad_swap16<NONNEG>(st.wpend, w);
+            const double rs = four_finish(x.su), r0 = four_finish(x.d0), r1 = four_finish(x.d1);
+            double rq = 0.0;
+            if (!NONNEG) rq = four_finish(x.q);
+            const int lane = threadIdx.x & 63, k = lane >> 4;
+            const long m = m0 + (((k & 1) << 1) | (k >> 1));
+            if ((lane & 15) == 0 && m >= m_lo && m < m_hi) {
+                sub[span_col + m] = rs;
+                spD0[span_col + m] = r0;
+                spD1[span_col + m] = r1;
+                if (!NONNEG) spQ0[span_col + m] = rq * (1.0 + 0x1p-12) + 1.0;
+            }
+        }
+    }
+}
+
 constexpr int kHypNone = -30000;      // "no hypothesis": every non-zero product overflows under it, the span is redone later
 
 // The lower of the two exponent hypotheses for a span: `guess` is last iteration's prefix sum at the span, rho the
@@ -476,15 +645,17 @@ constexpr int kHypNone = -30000;      // "no hypothesis": every non-zero product
 // this with the same arguments.
 __device__ __forceinline__ int hyp_exponent(double guess, double rho)
 {
-    const double v = fabs(guess * rho);
-    if (!(v >= 0x1p-1000) || !(v <= 0x1p1000)) return kHypNone;
-    int ex;
-    const double m = frexp(v, &ex);                   // v = m * 2^ex, m in [0.5, 1)
-    return (m < 0.70710678118654752) ? ex - 2 : ex - 1;
+    // read off the bits of |guess * rho| = f * 2^e, f in [1, 2): binades e-1, e when f < sqrt 2 (judged by the
+    // upper 20 bits of the fraction, which is all a heuristic needs), e, e+1 otherwise
+    const int hi = __double2hiint(guess * rho);
+    const int be = (hi >> 20) & 0x7ff;
+    const int e = be - 1023;
+    const int lower = ((hi & 0xfffff) < 0x6a09e) ? e - 1 : e;
+    return (be >= 23 && be <= 2023) ? lower : kHypNone;
 }
 
 template <int VEC, int MODE, bool WRITE_Q, int PF, bool CONTIG, int NH = 0>
-__global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
+__global__ __launch_bounds__(kBlock, (MODE == 3) ? 2 : 1) void k_stencil(const StencilArgs a)
 {
     constexpr bool FUSE_D = (MODE == 1 || MODE >= 3);                // operands are d and g, d' is formed here
     constexpr bool STORE_D = (MODE == 1 || MODE == 4 || MODE == 5);
@@ -511,8 +682,10 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     const long G = a.G;
     const long c0 = strip * W;
     const long j = c0 + (long)tid * VEC;
-    const long r0 = a.row_lo + lrt * a.tile_h;
-    const long r1 = (r0 + a.tile_h < a.row_hi) ? r0 + a.tile_h : a.row_hi;
+    // row numbers are 32-bit (the scalar unit compares those directly; a block has far fewer than 2^31 rows)
+    const int r0 = (int)(a.row_lo + lrt * a.tile_h);
+    const int r1 = (r0 + a.tile_h < (int)a.row_hi) ? r0 + a.tile_h : (int)a.row_hi;
+    const int nrows = (int)a.rows;
     const int rowbytes = (int)(G * 8);
     const bool left_edge = (tid == 0) && (c0 > 0);
     const bool right_edge = (tid == kBlock - 1) && (c0 + W < G);
@@ -547,28 +720,58 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
 
     // Row r of the block, r in [-1, rows]; -1 and rows are the halo rows (nullptr at
     // the global boundary).  Everything here is wave-uniform scalar arithmetic.
-    auto row_ptr = [&](const double *base, const double *top, const double *bot, long r) -> const double * {
-        return (r < 0) ? top : ((r >= a.rows) ? bot : base + r * G);
+    auto row_ptr = [&](const double *base, const double *top, const double *bot, int r) -> const double * {
+        return (r < 0) ? top : ((r >= nrows) ? bot : base + (long)r * G);
     };
-    auto load_row = [&](long r, RawRow<VEC> &raw) {
-        const bool live = r <= r1;                    // rows past the tile's lower halo are not needed
-        const double *pd = CONTIG ? a.d_in + r * G : row_ptr(a.d_in, a.d_top, a.d_bot, r);
-        const __amdgpu_buffer_rsrc_t rd = CONTIG ? row_rsrc_nn(pd, live ? rowbytes : 0) : row_rsrc(pd, live ? rowbytes : 0);
-        BufIO<VEC>::load(rd, off_main, raw.d);
-        raw.ed = buf_load1(rd, off_edge);
-        if (FUSE_D) {
-            const double *pg = CONTIG ? a.g + r * G : row_ptr(a.g, a.g_top, a.g_bot, r);
-            const __amdgpu_buffer_rsrc_t rg = CONTIG ? row_rsrc_nn(pg, live ? rowbytes : 0) : row_rsrc(pg, live ? rowbytes : 0);
-            BufIO<VEC>::load(rg, off_main, raw.g);
-            raw.eg = buf_load1(rg, off_edge);
+    // CONTIG: one descriptor per operand for the whole tile -- rows r0-1 .. r1 of the inputs, rows r0 .. r1-1 of what
+    // only the tile's own rows need -- and the row chosen by a scalar byte offset, clamped to the descriptor's size:
+    // a row outside the tile then fails the hardware range check like a column outside the grid (the host keeps
+    // tiles below 2^31 bytes).  That is one scalar multiply and one minimum per row instead of a descriptor per
+    // row and operand.
+    const unsigned in_bytes = (unsigned)(r1 - r0 + 2) * (unsigned)rowbytes, own_bytes = (unsigned)(r1 - r0) * (unsigned)rowbytes;
+    const __amdgpu_buffer_rsrc_t td = row_rsrc_nn(a.d_in + (long)(r0 - 1) * G, CONTIG ? (int)in_bytes : 0);
+    const __amdgpu_buffer_rsrc_t tg = row_rsrc_nn((FUSE_D ? a.g : a.d_in) + (long)(r0 - 1) * G, (CONTIG && FUSE_D) ? (int)in_bytes : 0);
+    const __amdgpu_buffer_rsrc_t tu = row_rsrc_nn(((MODE == 2 || MODE == 5) ? a.u : a.d_in) + (long)r0 * G,
+                                                  (CONTIG && (MODE == 2 || MODE == 5)) ? (int)own_bytes : 0);
+    const __amdgpu_buffer_rsrc_t tgw = row_rsrc_nn(((MODE == 2) ? a.gw : a.d_in) + (long)r0 * G, (CONTIG && MODE == 2) ? (int)own_bytes : 0);
+    auto umin = [](unsigned x, unsigned y) { return x < y ? x : y; };
+    auto load_row = [&](int r, RawRow<VEC> &raw) {
+        if constexpr (CONTIG) {
+            const int so = (int)umin((unsigned)(r - r0 + 1) * (unsigned)rowbytes, in_bytes);      // r >= r0 - 1
+            buf_load2s(td, off_main, so, raw.d);
+            raw.ed = buf_load1s(td, off_edge, so);
+            if (FUSE_D) {
+                buf_load2s(tg, off_main, so, raw.g);
+                raw.eg = buf_load1s(tg, off_edge, so);
+            } else {
+                raw.eg = 0.0;
+            }
+            if (NH > 0) raw.hyp = buf_load1(hyp_rsrc, (r >= 0 && r < nrows) ? r * 8 : kOOB);
+            if (MODE == 2 || MODE == 5) {
+                const int sou = (int)umin((unsigned)(r - r0) * (unsigned)rowbytes, own_bytes);    // r0 - 1 wraps round and is clamped
+                buf_load2s(tu, off_main, sou, raw.u);
+                if (MODE == 2) buf_load2s(tgw, off_main, sou, raw.g);
+            }
         } else {
-            raw.eg = 0.0;
-        }
-        if (NH > 0) raw.hyp = buf_load1(hyp_rsrc, (r >= 0 && r < a.rows) ? (int)(r * 8) : kOOB);
-        if (MODE == 2 || MODE == 5) {
-            const bool own = (r >= r0) && (r < r1);
-            BufIO<VEC>::load(row_rsrc_nn(a.u +r * G, own ? rowbytes : 0), off_main, raw.u);
-            if (MODE == 2) BufIO<VEC>::load(row_rsrc_nn(a.gw +r * G, own ? rowbytes : 0), off_main, raw.g);
+            const bool live = r <= r1;                    // rows past the tile's lower halo are not needed
+            const double *pd = row_ptr(a.d_in, a.d_top, a.d_bot, r);
+            const __amdgpu_buffer_rsrc_t rd = row_rsrc(pd, live ? rowbytes : 0);
+            BufIO<VEC>::load(rd, off_main, raw.d);
+            raw.ed = buf_load1(rd, off_edge);
+            if (FUSE_D) {
+                const double *pg = row_ptr(a.g, a.g_top, a.g_bot, r);
+                const __amdgpu_buffer_rsrc_t rg = row_rsrc(pg, live ? rowbytes : 0);
+                BufIO<VEC>::load(rg, off_main, raw.g);
+                raw.eg = buf_load1(rg, off_edge);
+            } else {
+                raw.eg = 0.0;
+            }
+            if (NH > 0) raw.hyp = buf_load1(hyp_rsrc, (r >= 0 && r < nrows) ? r * 8 : kOOB);
+            if (MODE == 2 || MODE == 5) {
+                const bool own = (r >= r0) && (r < r1);
+                BufIO<VEC>::load(row_rsrc_nn(a.u + (long)r * G, own ? rowbytes : 0), off_main, raw.u);
+                if (MODE == 2) BufIO<VEC>::load(row_rsrc_nn(a.gw + (long)r * G, own ? rowbytes : 0), off_main, raw.g);
+            }
         }
     };
 
@@ -584,14 +787,16 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
     int buf = 0;
     // Rows r0-1 .. r1 in groups of PF; a group may run past r1, those rows are fully
     // masked (zero loads, dropped stores, zero contributions to the partial sum).
-    for (long rb = r0 - 1; rb <= r1; rb += PF) {
-        SpanEntry ent[(NH > 0 && !SPAN_LDS) ? PF : 1];
-        bool ent_t0[(NH > 0 && !SPAN_LDS) ? PF : 1], ent_t1[(NH > 0 && !SPAN_LDS) ? PF : 1];
+    // NH > 0: the span sums of a batch of four or eight rows are reduced over the wavefront together (span4_push,
+    // span8_push); a kernel that keeps fewer than four rows in flight goes through its ring twice or four times per batch.
+    constexpr int BATCH = (NH > 0 && CG_SPAN_GROUPED && !SPAN_LDS && PF < 4) ? 4 : PF;
+    for (int rb = r0 - 1; rb <= r1; rb += BATCH) {
+        Span8 span8;
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const long r = rb + p;
-            const RawRow<VEC> raw = ring[p];
-            load_row(r + PF, ring[p]);                // refill the slot: PF rows in flight
+        for (int p = 0; p < BATCH; ++p) {
+            const int r = rb + p;
+            const RawRow<VEC> raw = ring[p % PF];
+            load_row(r + PF, ring[p % PF]);           // refill the slot: PF rows in flight
 
             double cur[VEC], edge;
             if (FUSE_D) {
@@ -603,11 +808,11 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 if (!STORE_D) {
                 } else if (CONTIG) {
                     const bool wr = (r >= r0 && r < r1) || (r < 0 && a.d_top_out != nullptr) ||
-                                    (r >= a.rows && r <= r1 && a.d_bot_out != nullptr);
-                    BufIO<VEC>::store(row_rsrc_nn(a.d_out + r * G, wr ? rowbytes : 0), off_main, cur);
+                                    (r >= nrows && r <= r1 && a.d_bot_out != nullptr);
+                    BufIO<VEC>::store(row_rsrc_nn(a.d_out + (long)r * G, wr ? rowbytes : 0), off_main, cur);
                 } else {
-                    const double *dst = (r >= r0 && r < r1) ? a.d_out + r * G
-                                      : ((r < 0) ? a.d_top_out : ((r >= a.rows && r <= r1) ? a.d_bot_out : nullptr));
+                    const double *dst = (r >= r0 && r < r1) ? a.d_out + (long)r * G
+                                      : ((r < 0) ? a.d_top_out : ((r >= nrows && r <= r1) ? a.d_bot_out : nullptr));
                     BufIO<VEC>::store(row_rsrc(dst, rowbytes), off_main, cur);
                 }
             } else {
@@ -630,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
             buf ^= 1;
 
             // Rows r-2 (up), r-1 (mid) and r (cur) are now in registers: emit row r-1.
-            const long m = r - 1;
+            const int m = r - 1;
             const long gi = a.row0 + m;
             const bool row_own = (m >= r0) && (m < r1);
             const bool row_in = row_own && (gi >= 1) && (gi <= G - 2);
@@ -643,9 +848,11 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                 if (a.coef.nine) {                                         // wave-uniform
                     const double ul = (v == 0) ? upL : up[v - 1], ur = (v == VEC - 1) ? upR : up[v + 1];
                     const double dl = (v == 0) ? curL : cur[v - 1], dr = (v == VEC - 1) ? curR : cur[v + 1];
-                    qv[v] = in ? nine_point(a.coef, ul, up[v], ur, left, mid[v], right, dl, cur[v], dr) : 0.0;
+                    const double q9 = nine_point(a.coef, ul, up[v], ur, left, mid[v], right, dl, cur[v], dr);
+                    qv[v] = in ? q9 : 0.0;
                 } else {
-                    qv[v] = in ? five_point(a.coef, up[v], left, mid[v], right, cur[v]) : 0.0;
+                    const double q5 = five_point(a.coef, up[v], left, mid[v], right, cur[v]);     // always evaluated: a select
+                    qv[v] = in ? q5 : 0.0;                                                        // costs less than a branch
                 }
             }
             if (MODE == 2) {
@@ -656,8 +863,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     pg[v] = mid_g[v] + tau * qv[v];
                     acc += pg[v] * pg[v];             // masked rows/lanes hold g = 0
                 }
-                BufIO<VEC>::store(row_rsrc_nn(a.u +m * G, row_own ? rowbytes : 0), off_main, pu);
-                BufIO<VEC>::store(row_rsrc_nn(a.gw +m * G, row_own ? rowbytes : 0), off_main, pg);
+                BufIO<VEC>::store(row_rsrc_nn(a.u +(long)m * G, row_own ? rowbytes : 0), off_main, pu);
+                BufIO<VEC>::store(row_rsrc_nn(a.gw +(long)m * G, row_own ? rowbytes : 0), off_main, pg);
                 if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
                     double span = pg[0] * pg[0];
                     span += pg[VEC - 1] * pg[VEC - 1];
@@ -671,7 +878,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     pg[v] = mid_g[v] + tau * qv[v];
                     acc += row_own ? pg[v] * pg[v] : 0.0;   // halo rows carry g too here: not ours to count
                 }
-                BufIO<VEC>::store(row_rsrc_nn(a.g_out + m * G, row_own ? rowbytes : 0), off_main, pg);
+                BufIO<VEC>::store(row_rsrc_nn(a.g_out + (long)m * G, row_own ? rowbytes : 0), off_main, pg);
                 if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
                     double prod[VEC];
 #pragma unroll
@@ -684,7 +891,12 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     } else if (!SPAN_LDS) {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                        span_reduce_store<true>(e, t0, t1, m, row_own, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        if (CG_SPAN_GROUPED && BATCH == 4)
+                            span4_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        else if (CG_SPAN_GROUPED && BATCH == 8)
+                            span8_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        else
+                            span_reduce_store<true>(e, t0, t1, m, row_own, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                     } else if (row_own) {                                      // wave-uniform
                         bool t0, t1;
                         constexpr int kRM = kSpanRows - 1;
@@ -704,7 +916,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                         pu[v] = mid_u[v] + tau_prev * mid_dp[v];     // cg.c:63-69 of the previous iteration
                         pu[v] = pu[v] + tau * mid[v];                // ... and of this one
                     }
-                    BufIO<VEC>::store(row_rsrc_nn(a.u + m * G, row_own ? rowbytes : 0), off_main, pu);
+                    BufIO<VEC>::store(row_rsrc_nn(a.u + (long)m * G, row_own ? rowbytes : 0), off_main, pu);
                 }
             } else {
                 double span = 0.0, prod[VEC];
@@ -731,8 +943,11 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                                 tiebits = 0;
                             }
                         }
-                    } else if (CG_SPAN_GROUPED) {
-                        ent[p] = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), ent_t0[p], ent_t1[p]);
+                    } else if (CG_SPAN_GROUPED && (BATCH == 8 || BATCH == 4)) {
+                        bool t0, t1;
+                        const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
+                        if (BATCH == 8) span8_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        else span4_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                     } else {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
@@ -745,7 +960,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
                     double out[VEC];
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) out[v] = a.store_products ? mid[v] * qv[v] : qv[v];
-                    const __amdgpu_buffer_rsrc_t rq = row_rsrc_nn(a.q + m * G, row_in ? rowbytes : 0);
+                    const __amdgpu_buffer_rsrc_t rq = row_rsrc_nn(a.q + (long)m * G, row_in ? rowbytes : 0);
                     BufIO<VEC>::store(rq, off_qv, out);
                     if (VEC == 2) {
                         buf_store1(rq, off_q0, out[0]);
@@ -760,14 +975,6 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs a)
             if (NH > 0) mid_hyp = raw.hyp;
             upL = midL; upR = midR;
             midL = curL; midR = curR;
-        }
-        if (NH > 0 && !SPAN_LDS && CG_SPAN_GROUPED && MODE == 3 && a.sub != nullptr) {
-#pragma unroll
-            for (int p = 0; p < PF; ++p) {                 // rows rb-1 .. rb+PF-2 were emitted in this group
-                const long m = rb + p - 1;
-                span_reduce_store<false>(ent[p], ent_t0[p], ent_t1[p], m, (m >= r0) && (m < r1), span_col, a.sub, a.spD0,
-                                         a.spQ0, a.spD1);
-            }
         }
     }
 
