@@ -1111,20 +1111,12 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
     }
 }
 
-#ifdef CG_DEBUG_XS
-// Diagnostic build only: the same dot product by the literal recurrence, and a comparison that reports.
-template <class Src>
-__global__ __launch_bounds__(64) void k_xs_literal(const Src src_in, long count, double start, double *result)
-{
-    Src src = src_in;
-    src.prepare();
-    const double s = replay(src, 0, count, start, (int)threadIdx.x);
-    if (threadIdx.x == 0) *result = s;
-}
-// Every usable chunk summary against one recomputed from the products under the same hypothesis.
+// Self-check (CG_OPT_STRICT_AUDIT): every usable chunk summary against one recomputed from the products under the
+// same hypothesis -- the sum must be the same integer, the stored extremes must enclose the true ones -- and the
+// result of the plan-driven walk against the hierarchical walk over the same summaries.  Failures are counted.
 template <class Src>
 __global__ __launch_bounds__(256) void k_xs_audit(const Src src_in, long count, const Summary *__restrict__ chunks, long nchunks,
-                                                  int which)
+                                                  unsigned long long *fails)
 {
     __shared__ __attribute__((aligned(16))) double T[4][Src::kLds];
     Src src = src_in;
@@ -1138,10 +1130,24 @@ __global__ __launch_bounds__(256) void k_xs_audit(const Src src_in, long count, 
         src.chunk16(lo, hi, lane, T[wv], p);
         Summary t = wave_compose_same_e(piece_summary(p, st.e), st.e);
         t.D = __shfl(t.D, 0, 64); t.mn = __shfl(t.mn, 0, 64); t.mx = __shfl(t.mx, 0, 64); t.bad = __shfl(t.bad, 0, 64);
-        if (lane == 0 && (t.bad || t.D != st.D || t.mn < st.mn || t.mx > st.mx))
-            printf("dot %d chunk %ld e %d: stored D %a mn %a mx %a | true D %a mn %a mx %a bad %d\n", which, c, st.e, st.D, st.mn,
-                   st.mx, t.D, t.mn, t.mx, t.bad);
+        if (lane == 0 && (t.bad || t.D != st.D || t.mn < st.mn || t.mx > st.mx)) atomicAdd(fails, 1ull);
     }
+}
+__global__ void k_xs_audit_result(const double *plan, const double *hier, unsigned long long *fails)
+{
+    const double a = *plan, b = *hier;
+    if (!(a == b || (a != a && b != b))) atomicAdd(fails, 1ull);
+}
+
+#ifdef CG_DEBUG_XS
+// Diagnostic build only: the same dot product by the literal recurrence, and a comparison that reports.
+template <class Src>
+__global__ __launch_bounds__(64) void k_xs_literal(const Src src_in, long count, double start, double *result)
+{
+    Src src = src_in;
+    src.prepare();
+    const double s = replay(src, 0, count, start, (int)threadIdx.x);
+    if (threadIdx.x == 0) *result = s;
 }
 __global__ void k_xs_compare(const double *plan, const double *hier, const double *lit, int which)
 {
@@ -1159,6 +1165,7 @@ struct Workspace {
     unsigned long long *marks = nullptr;  // per group: the chunks the walk is expected to take apart
     int *plist = nullptr, *pexp = nullptr, *pn = nullptr;  // the plan: those chunks in order, their predicted binades, how many
     double *dump = nullptr;               // their products and prepared pieces (kEntry doubles each)
+    unsigned long long *audit = nullptr;  // [0] failures counted by the self-check, [1] scratch (its second result)
     long cap_chunks = 0;
     // speculative path (reserve_spec): span sums under two hypotheses, the hypotheses of the two dot products of
     // an iteration (they persist from one iteration to the next), the repair list
@@ -1188,6 +1195,8 @@ struct Workspace {
         if ((e = hipMalloc(&pexp, (size_t)kPlanCap * sizeof(int))) != hipSuccess) return e;
         if ((e = hipMalloc(&pn, 256)) != hipSuccess) return e;
         if ((e = hipMemset(pn, 0, 256)) != hipSuccess) return e;
+        if ((e = hipMalloc(&audit, 256)) != hipSuccess) return e;
+        if ((e = hipMemset(audit, 0, 256)) != hipSuccess) return e;
         if ((e = hipMalloc(&dump, (size_t)(kPlanCap + 1) * kEntry * sizeof(double))) != hipSuccess) return e;
         cap_chunks = nc;
         return hipSuccess;
@@ -1232,10 +1241,10 @@ struct Workspace {
     {
         release_spec();
         (void)hipFree(approx); (void)hipFree(goff); (void)hipFree(chunks); (void)hipFree(groups); (void)hipFree(supers);
-        (void)hipFree(sub); (void)hipFree(stats); (void)hipFree(marks); (void)hipFree(plist); (void)hipFree(pexp); (void)hipFree(pn);
+        (void)hipFree(sub); (void)hipFree(stats); (void)hipFree(marks); (void)hipFree(plist); (void)hipFree(pexp); (void)hipFree(pn); (void)hipFree(audit);
         (void)hipFree(dump);
         approx = nullptr; goff = nullptr; chunks = nullptr; groups = nullptr; supers = nullptr; sub = nullptr; stats = nullptr;
-        marks = nullptr; plist = nullptr; pexp = nullptr; pn = nullptr; dump = nullptr;
+        marks = nullptr; plist = nullptr; pexp = nullptr; pn = nullptr; dump = nullptr; audit = nullptr;
         cap_chunks = 0;
     }
 };
@@ -1291,7 +1300,7 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
 // nonneg: every product is >= 0 (a vector with itself), the kernel stored no Q arrays.
 template <class Src>
 inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, long G, long rows, int which, bool nonneg,
-                         const double *rho_dev, double start, double *result)
+                         const double *rho_dev, double start, double *result, bool audit = false)
 {
     const long count = G * rows;
     const long nc = Workspace::chunks_for(count);
@@ -1313,14 +1322,18 @@ inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, lon
                        ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump);
     hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
                        start, (const double *)nullptr, result, ws.stats + 8 * which, ws.plist, ws.pexp, ws.pn, ws.dump);
+    if (audit) {
+        double *second = reinterpret_cast<double *>(ws.audit + 1);
+        hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
+                           start, (const double *)nullptr, second, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
+                           (const int *)nullptr, (const double *)nullptr);
+        hipLaunchKernelGGL(k_xs_audit<Src>, dim3(256), dim3(256), 0, s, src, count, ws.chunks, nc, ws.audit);
+        hipLaunchKernelGGL(k_xs_audit_result, dim3(1), dim3(1), 0, s, result, second, ws.audit);
+    }
 #ifdef CG_DEBUG_XS
     double *dbg = reinterpret_cast<double *>(ws.stats + 24);
-    hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, (const double *)nullptr, dbg, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
-                       (const int *)nullptr, (const double *)nullptr);
-    hipLaunchKernelGGL(k_xs_audit<Src>, dim3(256), dim3(256), 0, s, src, count, ws.chunks, nc, which);
     hipLaunchKernelGGL(k_xs_literal<Src>, dim3(1), dim3(64), 0, s, src, count, start, dbg + 1);
-    hipLaunchKernelGGL(k_xs_compare, dim3(1), dim3(1), 0, s, result, dbg, dbg + 1, which);
+    hipLaunchKernelGGL(k_xs_compare, dim3(1), dim3(1), 0, s, result, dbg + 1, dbg + 1, which);
 #endif
 }
 

@@ -275,6 +275,7 @@ struct cg_ctx {
     cg::Coef9 coef = kPoisson9;           // stencil coefficients (cg_set_stencil)
     int strict_impl = kStrictAuto;
     int strict_spec = 1;                  // lean schedule, strict order: summarise the products inside the passes
+    int strict_audit = 0;                 // ... and check every summary and walk against a recomputation (self-test, slow)
     long strict_blocks = 0;               // s > 1: sum in the layout of the reference on s*s ranks
     double *pack[2] = {nullptr, nullptr}; // one rank's block of v and w, contiguous
     double *block_sums = nullptr;         // its s*s sequential sums
@@ -574,7 +575,7 @@ int enqueue_lean_iteration(cg_ctx *c)
         cg::exact::SrcStencil src;
         src.d = c->d[in]; src.g = c->g; src.sc = c->sc; src.coef = c->coef;
         src.G = c->G; src.rows = c->rows; src.row0 = c->row0; src.count = c->count; src.beta = 0.0;
-        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, c->strict_slot);
+        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, c->strict_slot, c->strict_audit != 0);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_dq, tq.ntiles, c->strict_slot, 1, c->sc, 0, 0.0,
                            c->hist, c->hist_cap, (const double *)a.partials2, tq.ntiles);
@@ -626,7 +627,7 @@ int enqueue_lean_iteration(cg_ctx *c)
     if (spec) {
         const int vec = ((reinterpret_cast<uintptr_t>(b.g_out)) & 15) == 0 ? 1 : 0;
         const cg::exact::SrcArrays src{b.g_out, b.g_out, c->count, vec};
-        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, c->strict_slot);
+        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, c->strict_slot, c->strict_audit != 0);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_gg, n_gg, c->strict_slot, 1, c->sc, with_u ? 1 : 4, 0.0,
                            c->hist, c->hist_cap);
@@ -1326,6 +1327,7 @@ int cg_set_option(cg_ctx *c, int key, long value)
         c->strict_blocks = value; break;
     case CG_OPT_OVERLAP: c->overlap = value ? 1 : 0; break;
     case CG_OPT_STRICT_SPEC: c->strict_spec = value ? 1 : 0; break;
+    case CG_OPT_STRICT_AUDIT: c->strict_audit = value ? 1 : 0; drop_graph(c); break;
     case CG_OPT_COMM_REHEARSAL:
         if (value && c->nranks != 1) return fail(CG_ERR_ARG, "the communication rehearsal is for single-rank contexts");
         c->rehearse = value ? 1 : 0; break;
@@ -1364,6 +1366,16 @@ int cg_get_option(cg_ctx *c, int key, long *value)
     case CG_OPT_TILE_WGS: *value = ctx_geom(c).max_wgs; break;
     case CG_OPT_OVERLAP: *value = c->overlap; break;
     case CG_OPT_STRICT_SPEC: *value = c->strict_spec; break;
+    case CG_OPT_STRICT_AUDIT: {                         // failures the self-check has counted so far (0 when it is off)
+        unsigned long long n = 0;
+        if (c->xs.audit) {
+            CGCHK(select_device(c->device));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(&n, c->xs.audit, sizeof n, hipMemcpyDeviceToHost));
+        }
+        *value = (long)n;
+        break;
+    }
     case CG_OPT_STRICT_MISSES: {
         int n = 0;
         if (c->xs.nfix) {

@@ -24,6 +24,7 @@ OPT_COMM_REHEARSAL = 14
 OPT_STRICT_SPEC = 15
 OPT_STRICT_MISSES = 16
 OPT_STRICT_EVENTS = 17
+OPT_STRICT_AUDIT = 18
 STRICT_AUTO, STRICT_REPLAY, STRICT_PARALLEL = 1, 2, 3
 VEC_U, VEC_G, VEC_D, VEC_Q = 0, 1, 2, 3
 

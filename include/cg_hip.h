@@ -174,6 +174,9 @@ typedef struct cg_ctx cg_ctx;
                                   dot product of the last solve and were redone (diagnostic of CG_OPT_STRICT_SPEC) */
 #define CG_OPT_STRICT_EVENTS 17 /* read only: chunks the last solve's final two ordered walks had to take apart element by
                                   element (binade crossings, half-way cases): 10^6 * (d.q walk) + (g.g walk) */
+#define CG_OPT_STRICT_AUDIT 18 /* self-test of CG_OPT_STRICT_SPEC (slow): 1 = after every dot product each chunk summary is
+                                  checked against one recomputed from the products, and the plan-driven walk against the
+                                  plain hierarchical one; cg_get_option returns the failures counted so far (must be 0) */
 #define CG_OPT_OVERLAP     13  /* several ranks, lean schedule: 1 (default) = the new gradient's boundary rows travel on a
                                   second stream while the rows between them are computed; 0 = exchange in line */
 #define CG_OPT_COMM_REHEARSAL 14 /* single-rank context with cg_comm_init: 1 = issue the per-iteration traffic of a

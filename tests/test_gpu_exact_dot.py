@@ -147,6 +147,24 @@ def test_strict_solve_matches_reference_at_speed(cg, oracle, golden, n, iters):
     assert float(seq_sum(oracle, s.vector(cg.VEC_U))).hex() == rec["sum_u_hex"]
 
 
+@pytest.mark.parametrize("n,iters", [(1023, 120), (2047, 40), (4095, 24)])
+def test_strict_summaries_pass_the_self_check(cg, n, iters):
+    # Every chunk summary the passes hand over (sums under the hypothesised binade, bounds of the running value)
+    # is compared with one recomputed from the products, after every dot product of the solve, and the
+    # plan-driven walk with the plain hierarchical one; the history must equal the literal replay's.
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT).init_problem()
+    s.set_option(cg.lib.OPT_STRICT_AUDIT, 1)
+    s.solve(iters)
+    assert s.get_option(cg.lib.OPT_STRICT_AUDIT) == 0
+    got = s.history(iters)
+    s.close()
+    lit = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_impl=cg.STRICT_REPLAY).init_problem()
+    lit.solve(iters)
+    want = lit.history(iters)
+    lit.close()
+    assert np.array_equal(bits(got), bits(want))
+
+
 def test_headline_16384_1000_strict_is_bit_identical_to_the_reference(cg, oracle, golden):
     # The headline configuration in the reference's own summation order: 2.7e8-term dot products,
     # 1000 iterations, and every bit of q1, q_init and sum(u) equals what the reference printed

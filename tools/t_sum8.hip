@@ -1,7 +1,7 @@
 // micro test of cg::wave_sum8: lane l holds v[p] = 1000*p + l; expected sum over lanes = 64000*p + 2016 in lanes 8p..8p+7
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../conjugate-gradient_amd/csrc/cg_kernels.hpp"
+#include "../conjugate-gradient_amd/csrc/cg_kernels.hpp"
 __global__ void k(double *out, float *outf)
 {
     double v[8]; float f[8];
