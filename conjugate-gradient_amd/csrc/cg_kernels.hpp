@@ -655,7 +655,10 @@ __device__ __forceinline__ int hyp_exponent(double guess, double rho)
 }
 
 template <int VEC, int MODE, bool WRITE_Q, int PF, bool CONTIG, int NH = 0>
-__global__ __launch_bounds__(kBlock, (MODE == 3) ? 2 : 1) void k_stencil(const StencilArgs a)
+// Resident workgroups per CU the register budget is cut for: one for the writing passes, two for the read-only pass,
+// three for the read-only pass that also forms the strict-order span sums (bound by its instruction stream, not by
+// memory: every further wavefront per SIMD helps) when it keeps at most two rows in flight (157 registers).
+__global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2) : 1) void k_stencil(const StencilArgs a)
 {
     constexpr bool FUSE_D = (MODE == 1 || MODE >= 3);                // operands are d and g, d' is formed here
     constexpr bool STORE_D = (MODE == 1 || MODE == 4 || MODE == 5);

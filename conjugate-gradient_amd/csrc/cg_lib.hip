@@ -138,6 +138,7 @@ struct TileGeom {
     int pf = 4;       // rows of loads in flight per thread (stand-alone entry point)
     int pf_mode[6] = {4, 4, 4, 4, 4, 4};   // ... per kernel mode (solver context)
     int pf_spec_read = 4;                  // ... of the read-only pass when it also forms the strict-order span sums
+    int wg_mult = 2;                       // workgroups per CU of the read-only pass
     int vec;          // 2 when rows are 16-byte aligned (even G), else 1
     int nstrips;
     int tile_h;
@@ -194,7 +195,7 @@ long launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
     a.row_lo = row_lo; a.row_hi = row_hi; a.part_base = part_base;
     a.ntiles_launch = nrt * t.nstrips;
     // The read-only pass gets two workgroups per CU: measured 6.6 TB/s against 5.6 with one.
-    const long cap = (MODE == 3) ? 2 * t.max_wgs : t.max_wgs;
+    const long cap = (MODE == 3) ? t.wg_mult * t.max_wgs : t.max_wgs;
     const long nwg = (cap > 0 && cap < a.ntiles_launch) ? cap : a.ntiles_launch;
     const dim3 grid((unsigned)nwg), block(kBlock);
 #define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C, NH>), grid, block, 0, s, a)
@@ -337,9 +338,9 @@ TileGeom ctx_geom(const cg_ctx *c)
     for (int m = 0; m < 6; ++m) t.pf_mode[m] = c->prefetch > 0 ? c->prefetch : auto_pf[m];
     if (c->prefetch_read > 0) t.pf_mode[3] = c->prefetch_read;
     // With the span sums of the strict order the read-only pass is bound by its instruction stream and its
-    // registers, not by memory latency: four rows in flight leave it 181 registers (two workgroups per CU without
-    // spilling; eight rows need more than 256) and the four-row batched reduction: 0.99 ms against 1.12 at 16384^2.
-    t.pf_spec_read = c->prefetch_read > 0 ? c->prefetch_read : (c->prefetch > 0 ? c->prefetch : 4);
+    // registers, not by memory latency: two rows in flight leave it 157 registers, enough for three workgroups
+    // per CU (dq_geom), and the four-row batched reduction does the rest.
+    t.pf_spec_read = c->prefetch_read > 0 ? c->prefetch_read : (c->prefetch > 0 ? c->prefetch : 2);
     t.pf = t.pf_mode[0];
     if (c->tile_wgs > 0) t.max_wgs = c->tile_wgs;
     t.contig = 1;
@@ -350,8 +351,23 @@ TileGeom ctx_geom(const cg_ctx *c)
 // reads and is fastest with two workgroups per CU; a row block too short to give it that many
 // tiles (one rank's share of a multi-GPU run) gets tiles of half the height there: 83 instead of
 // 92 us at 2048 x 16384.  The g.g kernels keep `t`; each dot product has its own partials.
+bool strict_speculative(const cg_ctx *c, const TileGeom &t);
+
 TileGeom dq_geom(const cg_ctx *c, TileGeom t)
 {
+    // Strict order with span sums formed in the pass: three workgroups per CU, each walking two tiles.
+    if (c->tile_h == 0 && t.max_wgs > 0 && c->reduce == CG_REDUCE_STRICT && t.pf_spec_read <= 2 && strict_speculative(c, t)) {
+        long per_strip = 3 * t.max_wgs / t.nstrips;
+        if (per_strip < 1) per_strip = 1;
+        long h = (c->rows + 2 * per_strip - 1) / (2 * per_strip);
+        if (h < 32) h = (c->rows + per_strip - 1) / per_strip;
+        if (h < 16) h = 16;
+        if (h > c->rows) h = c->rows;
+        t.tile_h = (int)h;
+        t.ntiles = (long)t.nstrips * ((c->rows + h - 1) / h);
+        t.wg_mult = 3;
+        return t;
+    }
     if (c->tile_h == 0 && t.max_wgs > 0 && t.ntiles < 2 * t.max_wgs && t.tile_h >= 64) {
         const long h = (t.tile_h + 1) / 2;
         t.tile_h = (int)h;
