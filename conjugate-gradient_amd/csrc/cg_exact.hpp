@@ -347,24 +347,40 @@ constexpr int kSub = 128;
 // at row m, column j sits at sub[(j/kSub)*rows + m], so that a wavefront walking down a column
 // strip writes consecutive doubles (scattered 8-byte stores, one per row a kilobyte apart, cost
 // the tiled kernels 20-35 % of their time).
+// gsum != nullptr: the pass over the groups (k_xs_gsum) is done here as well -- thread t of a workgroup holds chunk
+// 256 b + t, so each of its four wavefronts holds one whole group.
 __global__ __launch_bounds__(256) void k_xs_from_sub(const double *__restrict__ sub, long nsub, long nchunks,
-                                                     long G, long rows, double *__restrict__ approx)
+                                                     long G, long rows, double *__restrict__ approx,
+                                                     double *__restrict__ gsum)
 {
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
     double acc = 0.0;
+    if (c < nchunks) {
 #pragma unroll
-    for (int j = 0; j < kChunk / kSub; ++j) {
-        const long i = c * (kChunk / kSub) + j;
-        if (i >= nsub) break;
-        if (G > 0) {
-            const long k = i * kSub, m = k / G, col = k - m * G;
-            acc += sub[(col / kSub) * rows + m];
-        } else {
-            acc += sub[i];
+        for (int j = 0; j < kChunk / kSub; ++j) {
+            const long i = c * (kChunk / kSub) + j;
+            if (i >= nsub) break;
+            if (G > 0) {
+                const long k = i * kSub, m = k / G, col = k - m * G;
+                acc += sub[(col / kSub) * rows + m];
+            } else {
+                acc += sub[i];
+            }
         }
     }
-    approx[c] = acc;
+    if (gsum == nullptr) {
+        if (c < nchunks) approx[c] = acc;
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    double inc = acc;                                // chunks beyond the end count zero
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += up;
+    }
+    if (c < nchunks) approx[c] = inc - acc;
+    if (lane == 63 && (c >> 6) * kGroup < nchunks) gsum[c >> 6] = inc;
 }
 
 // Sum of each group's 64 chunk sums; the chunk sums themselves are replaced by their exclusive
@@ -586,7 +602,7 @@ __global__ __launch_bounds__(256) void k_sp_fix(const Src src_in, long count, co
 // A wrong mark costs time only: the walk judges every summary by the true accumulator.
 constexpr int kPlanCap = 1024;                  // chunks whose products are staged for the walk (8 KiB each)
 constexpr double kPlanMargin = 0x1p26;          // ulps; the approximate prefix sums are far more accurate than that
-constexpr int kPlanBlocks = 32;                 // workgroups that stage them
+constexpr int kPlanBlocks = 64;                 // workgroups that stage them
 constexpr int kMarkBit = 2;                     // Summary::bad of a group summary: the group is expected not to apply
 
 // Will the walk, arriving with an accumulator close to `guess`, probably reject this summary?
@@ -898,17 +914,21 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
         for (int k = t; k < n; k += 256) plist[k] = clist[k];
         if (t == 0) *pn = n;
     }
-    for (int k = blockIdx.x * 4 + wv; k <= n; k += gridDim.x * 4) {
+    // 2n + 1 pieces of work, one wavefront each: the n + 1 stretch summaries, then the n chunks
+    for (int item = blockIdx.x * 4 + wv; item <= 2 * n; item += gridDim.x * 4) {
+        const int k = (item <= n) ? item : item - n - 1;
         double *ent = dump + (long)k * kEntry;
-        const long from = (k == 0) ? 0 : (long)clist[k - 1] + 1, to = (k < n) ? (long)clist[k] : nchunks;
-        const Summary st = stretch_summary(chunks, groups, supers, from, to, lane);
-        if (lane == 0) {
-            xv2 *ps = reinterpret_cast<xv2 *>(ent + kChunk + 64 * kPieceDoubles);
-            xv2 v0, v1;
-            v0.x = st.D; v0.y = st.mn; v1.x = st.mx; v1.y = __hiloint2double(st.bad & 1, st.e);
-            ps[0] = v0; ps[1] = v1;
+        if (item <= n) {
+            const long from = (k == 0) ? 0 : (long)clist[k - 1] + 1, to = (k < n) ? (long)clist[k] : nchunks;
+            const Summary st = stretch_summary(chunks, groups, supers, from, to, lane);
+            if (lane == 0) {
+                xv2 *ps = reinterpret_cast<xv2 *>(ent + kChunk + 64 * kPieceDoubles);
+                xv2 v0, v1;
+                v0.x = st.D; v0.y = st.mn; v1.x = st.mx; v1.y = __hiloint2double(st.bad & 1, st.e);
+                ps[0] = v0; ps[1] = v1;
+            }
+            continue;
         }
-        if (k == n) break;
         const long c = clist[k];
         const long lo = c * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
         double p[kPerLane];
@@ -1272,19 +1292,20 @@ inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const d
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
     const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4);
-    if (have_sub)
+    if (have_sub) {
         hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub,
-                           (count + kSub - 1) / kSub, nc, sub_G, sub_rows, ws.approx);
-    else
+                           (count + kSub - 1) / kSub, nc, sub_G, sub_rows, ws.approx, ws.goff);
+    } else {
         hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
-    hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
+        hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
+    }
     hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, start_dev);
     const unsigned cbp = cb < 1024u ? cb : 1024u;          // persistent: the four workgroups per CU that LDS allows
     if (w != nullptr)
         hipLaunchKernelGGL(k_xs_chunk<true>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
     else
         hipLaunchKernelGGL(k_xs_chunk<false>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
-    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
+    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
     const long nsup = (ng + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((nsup + 3) / 4)), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup,
                        (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr);
@@ -1305,16 +1326,14 @@ inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, lon
     const long count = G * rows;
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
-    const unsigned gb = (unsigned)((ng + 3) / 4);
     hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub, (count + kSub - 1) / kSub,
-                       nc, G, rows, ws.approx);
-    hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
+                       nc, G, rows, ws.approx, ws.goff);
     hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, (const double *)nullptr, ws.nfix);
     const long nwave = ((rows + 63) / 64) * (G / kChunk);
     hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, ws.sub, ws.spD0,
                        nonneg ? (const double *)nullptr : ws.spQ0, ws.spD1, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
-    hipLaunchKernelGGL(k_sp_fix<Src>, dim3(1024), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
-    hipLaunchKernelGGL(k_xs_group, dim3(gb), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
+    hipLaunchKernelGGL(k_sp_fix<Src>, dim3(256), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
+    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
     const long nsup = (ng + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((nsup + 3) / 4)), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup,
                        (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr);
