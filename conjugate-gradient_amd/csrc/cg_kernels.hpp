@@ -377,25 +377,13 @@ struct RawRow {
 // magnitudes is at most their total, and |partial D| <= partial Q); a half-way case anywhere in the span turns
 // that hypothesis' D into a NaN.
 // The sums over the 64 lanes are NOT formed row by row (four dependent data-parallel reductions per row cost
-// more than the rest of the pass): every lane parks its own contribution in LDS, and after eight rows the
-// wavefront adds them up transposed -- lane (r, s) the s-th eighth of row r, three exchange steps between the
-// eighths -- and eight lanes store eight consecutive rows of each span array at once.
+// more than the rest of the pass): the entries of four or eight consecutive rows are reduced together in
+// registers, the lanes trading rows (span4_push / span8_push below).
 struct SpanEntry {
     double sub, D0, D1;
     float qf;
     int pad;
 };
-#ifndef CG_SPAN_LDS_MIN_MODE
-#define CG_SPAN_LDS_MIN_MODE 99
-#endif
-#ifndef CG_SPAN_GROUPED
-#define CG_SPAN_GROUPED 1
-#endif
-#ifndef CG_SPAN_ROWS
-#define CG_SPAN_ROWS 8
-#endif
-constexpr int kSpanRows = CG_SPAN_ROWS;          // rows per batch (8 or 4)
-constexpr int kSpanStride = 65;       // entries per row in LDS: odd, so that the transposed 16-byte reads spread over the banks
 
 template <int VEC, bool NONNEG>
 __device__ __forceinline__ SpanEntry span_entry(const double (&p)[VEC], int e0, bool &tie0, bool &tie1)
@@ -418,11 +406,6 @@ __device__ __forceinline__ SpanEntry span_entry(const double (&p)[VEC], int e0, 
     return s;
 }
 
-__device__ __forceinline__ double xor_add(double v, int mask)
-{
-    return v + __shfl_xor(v, mask, 64);
-}
-
 // The same sums for ONE row by data-parallel reductions inside the wavefront (result in lane 63, which stores).
 // Called for several buffered rows in a row, so that their dependent reduction chains interleave.
 template <bool NONNEG>
@@ -440,45 +423,6 @@ __device__ __forceinline__ void span_reduce_store(const SpanEntry &e, bool tie0,
         spD0[span_col + m] = d0;
         spD1[span_col + m] = d1;
         if (!NONNEG) spQ0[span_col + m] = (double)qf * (1.0 + 0x1p-12) + 1.0;
-    }
-}
-
-// Adds up a batch of parked rows and stores them.  red: this wavefront's kSpanRows x kSpanStride entries; rows
-// mb .. mb+7 of the block are in the batch, of which [m_lo, m_hi] are to be stored; tiebits: bit r (hypothesis
-// e0) and bit 8+r (e0+1) say that row mb+r held a half-way case.
-template <bool NONNEG>
-__device__ __forceinline__ void span_flush(const SpanEntry *red, long mb, long m_lo, long m_hi, unsigned tiebits,
-                                           long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
-{
-    const int lane = threadIdx.x & 63;
-    const int r = lane & (kSpanRows - 1), sg = lane / kSpanRows;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double su = 0.0, d0 = 0.0, d1 = 0.0;
-    float qf = 0.0f;
-    const SpanEntry *row = red + r * kSpanStride + sg * kSpanRows;
-#pragma unroll
-    for (int i = 0; i < kSpanRows; ++i) {
-        const SpanEntry e = row[i];
-        su += e.sub; d0 += e.D0; d1 += e.D1;
-        if (!NONNEG) qf += e.qf;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // all reads done before the next batch's writes
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int mask = kSpanRows; mask < 64; mask <<= 1) {          // the parts of a row sit kSpanRows lanes apart
-        su = xor_add(su, mask); d0 = xor_add(d0, mask); d1 = xor_add(d1, mask);
-        if (!NONNEG) qf += __shfl_xor(qf, mask, 64);
-    }
-    const long m = mb + r;
-    if (sg == 0 && m >= m_lo && m <= m_hi) {
-        if ((tiebits >> r) & 1u) d0 = __builtin_nan("");
-        if ((tiebits >> (kSpanRows + r)) & 1u) d1 = __builtin_nan("");
-        sub[span_col + m] = su;
-        spD0[span_col + m] = d0;
-        spD1[span_col + m] = d1;
-        if (!NONNEG) spQ0[span_col + m] = (double)qf * (1.0 + 0x1p-12) + 1.0;   // 2 x 64 roundings of 2^-24 each, far below 2^-12
     }
 }
 
@@ -667,14 +611,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
 
     __shared__ double row_lds[2][W + 2];
     __shared__ double wave_slots[kWaves];
-    // NH > 0: where the per-lane contributions to the span sums wait for their reduction over the wavefront --
-    // the read-only pass keeps those of a whole group of PF rows in registers and reduces them together (measured:
-    // parking them in LDS costs that pass a quarter of its speed), the writing passes park eight rows in LDS.
-    constexpr bool SPAN_LDS = (NH > 0) && (MODE >= CG_SPAN_LDS_MIN_MODE);
-    __shared__ __attribute__((aligned(16))) SpanEntry span_lds[SPAN_LDS ? kWaves * kSpanRows * kSpanStride : 1];
-    SpanEntry *const red = span_lds + (SPAN_LDS ? (threadIdx.x >> 6) * kSpanRows * kSpanStride : 0);
-    unsigned tiebits = 0;
-
     const int tid = threadIdx.x;
     const long nwg = (long)gridDim.x;
     // A launch may have fewer workgroups than tiles: workgroup b then walks tiles
@@ -792,7 +728,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     // masked (zero loads, dropped stores, zero contributions to the partial sum).
     // NH > 0: the span sums of a batch of four or eight rows are reduced over the wavefront together (span4_push,
     // span8_push); a kernel that keeps fewer than four rows in flight goes through its ring twice or four times per batch.
-    constexpr int BATCH = (NH > 0 && CG_SPAN_GROUPED && !SPAN_LDS && PF < 4) ? 4 : PF;
+    constexpr int BATCH = (NH > 0 && PF < 4) ? 4 : PF;
     for (int rb = r0 - 1; rb <= r1; rb += BATCH) {
         Span8 span8;
 #pragma unroll
@@ -891,25 +827,15 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                     if (NH == 0) {
                         span = wave_sum_unordered(span);
                         if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
-                    } else if (!SPAN_LDS) {
+                    } else {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                        if (CG_SPAN_GROUPED && BATCH == 4)
+                        if (BATCH == 4)
                             span4_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                        else if (CG_SPAN_GROUPED && BATCH == 8)
+                        else if (BATCH == 8)
                             span8_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                         else
                             span_reduce_store<true>(e, t0, t1, m, row_own, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                    } else if (row_own) {                                      // wave-uniform
-                        bool t0, t1;
-                        constexpr int kRM = kSpanRows - 1;
-                        red[(m & kRM) * kSpanStride + (tid & 63)] = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                        tiebits |= ((__ballot(t0) != 0ull) ? 1u : 0u) << (m & kRM);
-                        tiebits |= ((__ballot(t1) != 0ull) ? 1u : 0u) << (kSpanRows + (m & kRM));
-                        if ((m & kRM) == kRM || m == r1 - 1) {
-                            span_flush<true>(red, m & ~(long)kRM, r0, m, tiebits, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                            tiebits = 0;
-                        }
                     }
                 }
                 if (MODE == 5) {
@@ -934,19 +860,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                     if (NH == 0) {
                         span = wave_sum_unordered(span);
                         if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
-                    } else if (SPAN_LDS) {
-                        if (row_own) {
-                            bool t0, t1;
-                            constexpr int kRM = kSpanRows - 1;
-                            red[(m & kRM) * kSpanStride + (tid & 63)] = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                            tiebits |= ((__ballot(t0) != 0ull) ? 1u : 0u) << (m & kRM);
-                            tiebits |= ((__ballot(t1) != 0ull) ? 1u : 0u) << (kSpanRows + (m & kRM));
-                            if ((m & kRM) == kRM || m == r1 - 1) {
-                                span_flush<false>(red, m & ~(long)kRM, r0, m, tiebits, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                                tiebits = 0;
-                            }
-                        }
-                    } else if (CG_SPAN_GROUPED && (BATCH == 8 || BATCH == 4)) {
+                    } else if (BATCH == 8 || BATCH == 4) {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
                         if (BATCH == 8) span8_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);

@@ -18,7 +18,7 @@
  *                   (row and column halos, corner points) instead of row blocks; with CG_STRICT=1 the output is
  *                   `mpirun -np P ./cg n` of the reference bit for bit
  *   CG_STRICT=1     dot products in the reference's exact summation order
- *                   (bit-identical results, about a third of the fast rate)
+ *                   (bit-identical results, about four fifths of the fast rate on one GPU)
  *   CG_STRICT_NP=P  with CG_STRICT=1 on one GPU: the summation layout of the reference run
  *                   on P = 4, 16 or 64 ranks, i.e. the bits of `mpirun -np P ./cg n`
  *   CG_SCHEDULE=classic|fused|fused_noq|lean   kernel schedule of the solve path
