@@ -256,7 +256,7 @@ def main():
                                    f"(BASELINE.json configs[{2 if world == 1 else 3}])",
                        "grid": G, "rows_per_gpu": rows, "schedule": args.schedule, "reduce": args.reduce,
                        "bytes_per_point_per_iter": bpp,
-                       "graph_iters": args.graph_iters if args.graph_iters is not None else (10 if world == 1 else 0),
+                       "graph_iters": s.get_option(cg.lib.OPT_GRAPH_ITERS), "overlap": s.get_option(cg.lib.OPT_OVERLAP) if world > 1 else 0,
                        "transport": transport, "parallelism": f"rowblocks{world}"},
             "hbm_gbs_per_gpu": bpp * rows * G * its / 1e9,
             "hbm_frac_of_peak": bpp * rows * G * its / 1e9 / HBM_PEAK_GBS,

@@ -165,6 +165,18 @@ def test_strict_summaries_pass_the_self_check(cg, n, iters):
     assert np.array_equal(bits(got), bits(want))
 
 
+def test_headline_16384_1000_strict_with_the_self_check_on(cg, golden):
+    # The headline run once more with every summary of every dot product audited (2000 dot products of 2.7e8 terms).
+    rec = golden.get((16383, 1000, 1, 0.0))
+    if rec is None:
+        pytest.skip("16383/1000 golden not generated")
+    s = cg.CGSolver(16383).configure(reduce=cg.REDUCE_STRICT).init_problem()
+    s.set_option(cg.lib.OPT_STRICT_AUDIT, 1)
+    r = s.solve(1000)
+    assert s.get_option(cg.lib.OPT_STRICT_AUDIT) == 0
+    assert float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex()
+
+
 def test_headline_16384_1000_strict_is_bit_identical_to_the_reference(cg, oracle, golden):
     # The headline configuration in the reference's own summation order: 2.7e8-term dot products,
     # 1000 iterations, and every bit of q1, q_init and sum(u) equals what the reference printed
