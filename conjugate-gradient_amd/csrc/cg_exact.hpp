@@ -404,12 +404,15 @@ __global__ __launch_bounds__(256) void k_xs_gsum(double *__restrict__ approx, lo
 }
 
 // In-place exclusive scan of the group sums, seeded with `start` (or, when `start_dev` is
-// given, with the device-resident value it points to).  One workgroup.
+// given, with the sum of the nstart device-resident values it points to).  One workgroup.
 __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, long ngroups, double start,
-                                                   const double *start_dev, int *zero_me = nullptr)
+                                                   const double *start_dev, int nstart, int *zero_me = nullptr)
 {
     if (zero_me != nullptr && threadIdx.x == 0) *zero_me = 0;      // the repair list of the speculative path starts empty
-    if (start_dev != nullptr) start = *start_dev;
+    if (start_dev != nullptr) {
+        start = 0.0;
+        for (int k = 0; k < nstart; ++k) start += start_dev[k];
+    }
     __shared__ double wave_tot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const long per = (ngroups + 1023) / 1024;
@@ -431,6 +434,23 @@ __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, lo
         const double x = gsum[g];
         gsum[g] = run;
         run += x;
+    }
+}
+
+// Sum of the (not yet scanned) group sums: this block's approximate total, for the ranks that come after it.
+__global__ __launch_bounds__(1024) void k_xs_total(const double *__restrict__ gsum, long ngroups, double *__restrict__ out)
+{
+    __shared__ double wave_tot[16];
+    double mine = 0.0;
+    for (long g = threadIdx.x; g < ngroups; g += 1024) mine += gsum[g];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += wave_tot[k];
+        *out = t;
     }
 }
 
@@ -1277,81 +1297,152 @@ struct Workspace {
 // produced v and w; sub_G > 0: in the by-rows layout of k_xs_from_sub), so the operands are read
 // once instead of twice.  Those sums only steer
 // the guesses; every guess is verified by the walk, so their accuracy affects speed, never bits.
-inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
-                    double *result, const double *start_dev = nullptr, bool have_sub = false, long sub_G = 0,
-                    long sub_rows = 0)
+//
+// Three phases, so that several ranks whose blocks follow one another in the index order can do the first two
+// side by side and only the walks one after the other:
+//   approx     approximate chunk sums and group sums (total_out: their total, for the ranks that come after)
+//   summaries  everything up to the plan, the guesses seeded with `start` or the sum of nseed device values (the
+//              approximate totals of the ranks before this one: a seed steers, it need not be exact)
+//   walk       the ordered walk from the exact accumulator
+struct Arrays {
+    const double *v, *w;
+    long count;
+    bool have_sub = false;
+    long sub_G = 0, sub_rows = 0;
+    int vec() const { return ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0; }   // (null w: v alone)
+    SrcArrays src() const { return SrcArrays{v, w, count > 0 ? count : 0, vec()}; }
+};
+
+inline void enqueue_approx(hipStream_t s, const Workspace &ws, const Arrays &a, double *total_out = nullptr)
 {
-    const int vec = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 ? 1 : 0;   // (null w: v alone)
-    const SrcArrays src{v, w, count > 0 ? count : 0, vec};
-    if (count <= 0) {
-        hipLaunchKernelGGL(k_xs_walk<SrcArrays>, dim3(1), dim3(64), 0, s, src, 0L, ws.chunks, 0L, ws.groups, 0L,
-                           start, start_dev, result, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
-                           (const int *)nullptr, (const double *)nullptr);
+    if (a.count <= 0) {
+        if (total_out) hipLaunchKernelGGL(k_xs_total, dim3(1), dim3(1024), 0, s, ws.goff, 0L, total_out);
         return;
     }
-    const long nc = Workspace::chunks_for(count);
+    const long nc = Workspace::chunks_for(a.count);
     const long ng = (nc + kGroup - 1) / kGroup;
-    const unsigned cb = (unsigned)((nc + 3) / 4), gb = (unsigned)((ng + 3) / 4);
-    if (have_sub) {
+    if (a.have_sub) {
         hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub,
-                           (count + kSub - 1) / kSub, nc, sub_G, sub_rows, ws.approx, ws.goff);
+                           (a.count + kSub - 1) / kSub, nc, a.sub_G, a.sub_rows, ws.approx, ws.goff);
     } else {
-        hipLaunchKernelGGL(k_xs_approx, dim3(cb), dim3(256), 0, s, v, w, count, nc, vec, ws.approx);
-        hipLaunchKernelGGL(k_xs_gsum, dim3(gb), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
+        hipLaunchKernelGGL(k_xs_approx, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, s, a.v, a.w, a.count, nc, a.vec(), ws.approx);
+        hipLaunchKernelGGL(k_xs_gsum, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
     }
-    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, start_dev);
-    const unsigned cbp = cb < 1024u ? cb : 1024u;          // persistent: the four workgroups per CU that LDS allows
-    if (w != nullptr)
-        hipLaunchKernelGGL(k_xs_chunk<true>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
-    else
-        hipLaunchKernelGGL(k_xs_chunk<false>, dim3(cbp), dim3(256), 0, s, v, w, count, nc, vec, ws.approx, ws.goff, ws.chunks);
-    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
-    const long nsup = (ng + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((nsup + 3) / 4)), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup,
-                       (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(k_xs_plan<SrcArrays>, dim3(kPlanBlocks), dim3(256), 0, s, src, count, ws.chunks, nc, ws.groups, ws.supers,
-                       ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump);
-    hipLaunchKernelGGL(k_xs_walk<SrcArrays>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, start_dev, result, ws.stats, ws.plist, ws.pexp, ws.pn, ws.dump);
+    if (total_out) hipLaunchKernelGGL(k_xs_total, dim3(1), dim3(1024), 0, s, ws.goff, ng, total_out);
 }
 
-// The same result from the speculative span sums the producing kernel left in the workspace (sub, spD*, spQ*
-// under the hypotheses ws.hyp[which]); `src` recomputes or re-reads single products where the walk or the
-// repair of missed chunks needs them.  The operands are `rows` rows of G products, G a multiple of kChunk.
-// nonneg: every product is >= 0 (a vector with itself), the kernel stored no Q arrays.
 template <class Src>
-inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, long G, long rows, int which, bool nonneg,
-                         const double *rho_dev, double start, double *result, bool audit = false)
+inline void enqueue_levels_and_plan(hipStream_t s, const Workspace &ws, const Src &src, long count)
 {
-    const long count = G * rows;
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub, (count + kSub - 1) / kSub,
-                       nc, G, rows, ws.approx, ws.goff);
-    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, (const double *)nullptr, ws.nfix);
-    const long nwave = ((rows + 63) / 64) * (G / kChunk);
-    hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, ws.sub, ws.spD0,
-                       nonneg ? (const double *)nullptr : ws.spQ0, ws.spD1, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
-    hipLaunchKernelGGL(k_sp_fix<Src>, dim3(256), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
     hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
     const long nsup = (ng + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((nsup + 3) / 4)), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup,
                        (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(k_xs_plan<Src>, dim3(kPlanBlocks), dim3(256), 0, s, src, count, ws.chunks, nc, ws.groups, ws.supers,
                        ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump);
-    hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, (const double *)nullptr, result, ws.stats + 8 * which, ws.plist, ws.pexp, ws.pn, ws.dump);
-    if (audit) {
-        double *second = reinterpret_cast<double *>(ws.audit + 1);
-        hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                           start, (const double *)nullptr, second, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
+}
+
+inline void enqueue_summaries(hipStream_t s, const Workspace &ws, const Arrays &a, double start, const double *seed_dev = nullptr,
+                              int nseed = 0)
+{
+    if (a.count <= 0) return;
+    const long nc = Workspace::chunks_for(a.count);
+    const long ng = (nc + kGroup - 1) / kGroup;
+    const unsigned cb = (unsigned)((nc + 3) / 4);
+    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, seed_dev, nseed, (int *)nullptr);
+    const unsigned cbp = cb < 1024u ? cb : 1024u;          // persistent: the four workgroups per CU that LDS allows
+    if (a.w != nullptr)
+        hipLaunchKernelGGL(k_xs_chunk<true>, dim3(cbp), dim3(256), 0, s, a.v, a.w, a.count, nc, a.vec(), ws.approx, ws.goff, ws.chunks);
+    else
+        hipLaunchKernelGGL(k_xs_chunk<false>, dim3(cbp), dim3(256), 0, s, a.v, a.w, a.count, nc, a.vec(), ws.approx, ws.goff, ws.chunks);
+    enqueue_levels_and_plan(s, ws, a.src(), a.count);
+}
+
+template <class Src>
+inline void enqueue_walk(hipStream_t s, const Workspace &ws, const Src &src, long count, double start, const double *start_dev,
+                         double *result, long *stats)
+{
+    if (count <= 0) {
+        hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, 0L, ws.chunks, 0L, ws.groups, 0L,
+                           start, start_dev, result, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
                            (const int *)nullptr, (const double *)nullptr);
-        hipLaunchKernelGGL(k_xs_audit<Src>, dim3(256), dim3(256), 0, s, src, count, ws.chunks, nc, ws.audit);
-        hipLaunchKernelGGL(k_xs_audit_result, dim3(1), dim3(1), 0, s, result, second, ws.audit);
+        return;
     }
+    const long nc = Workspace::chunks_for(count);
+    const long ng = (nc + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
+                       start, start_dev, result, stats, ws.plist, ws.pexp, ws.pn, ws.dump);
+}
+
+inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
+                    double *result, const double *start_dev = nullptr, bool have_sub = false, long sub_G = 0,
+                    long sub_rows = 0)
+{
+    Arrays a{v, w, count, have_sub, sub_G, sub_rows};
+    enqueue_approx(s, ws, a);
+    enqueue_summaries(s, ws, a, start, start_dev, start_dev ? 1 : 0);
+    enqueue_walk(s, ws, a.src(), count, start, start_dev, result, ws.stats);
+}
+
+// The same result from the speculative span sums the producing kernel left in the workspace (sub, spD*, spQ*
+// under the hypotheses ws.hyp[which]); `src` recomputes or re-reads single products where the walk or the
+// repair of missed chunks needs them.  The operands are `rows` rows of G products, G a multiple of kChunk.
+// nonneg: every product is >= 0 (a vector with itself), the kernel stored no Q arrays.
+// The three phases for the span sums: spec_approx, spec_summaries, and enqueue_walk above.
+inline void spec_approx(hipStream_t s, const Workspace &ws, long G, long rows, double *total_out = nullptr)
+{
+    const long count = G * rows;
+    const long nc = Workspace::chunks_for(count);
+    const long ng = (nc + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub, (count + kSub - 1) / kSub,
+                       nc, G, rows, ws.approx, ws.goff);
+    if (total_out) hipLaunchKernelGGL(k_xs_total, dim3(1), dim3(1024), 0, s, ws.goff, ng, total_out);
+}
+
+template <class Src>
+inline void spec_summaries(hipStream_t s, const Workspace &ws, const Src &src, long G, long rows, int which, bool nonneg,
+                           const double *rho_dev, double start, const double *seed_dev = nullptr, int nseed = 0)
+{
+    const long count = G * rows;
+    const long nc = Workspace::chunks_for(count);
+    const long ng = (nc + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, seed_dev, nseed, ws.nfix);
+    const long nwave = ((rows + 63) / 64) * (G / kChunk);
+    hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, ws.sub, ws.spD0,
+                       nonneg ? (const double *)nullptr : ws.spQ0, ws.spD1, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
+    hipLaunchKernelGGL(k_sp_fix<Src>, dim3(256), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
+    enqueue_levels_and_plan(s, ws, src, count);
+}
+
+// The self-check of CG_OPT_STRICT_AUDIT for a dot product whose walk has just written `result`.
+template <class Src>
+inline void enqueue_audit(hipStream_t s, const Workspace &ws, const Src &src, long count, double start, const double *start_dev,
+                          const double *result)
+{
+    const long nc = Workspace::chunks_for(count);
+    const long ng = (nc + kGroup - 1) / kGroup;
+    double *second = reinterpret_cast<double *>(ws.audit + 1);
+    hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
+                       start, start_dev, second, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
+                       (const int *)nullptr, (const double *)nullptr);
+    hipLaunchKernelGGL(k_xs_audit<Src>, dim3(256), dim3(256), 0, s, src, count, ws.chunks, nc, ws.audit);
+    hipLaunchKernelGGL(k_xs_audit_result, dim3(1), dim3(1), 0, s, result, second, ws.audit);
+}
+
+// One rank: all three in a row.
+template <class Src>
+inline void enqueue_spec(hipStream_t s, const Workspace &ws, const Src &src, long G, long rows, int which, bool nonneg,
+                         const double *rho_dev, double start, double *result, bool audit = false)
+{
+    spec_approx(s, ws, G, rows);
+    spec_summaries(s, ws, src, G, rows, which, nonneg, rho_dev, start);
+    enqueue_walk(s, ws, src, G * rows, start, (const double *)nullptr, result, ws.stats + 8 * which);
+    if (audit) enqueue_audit(s, ws, src, G * rows, start, (const double *)nullptr, result);
 #ifdef CG_DEBUG_XS
     double *dbg = reinterpret_cast<double *>(ws.stats + 24);
-    hipLaunchKernelGGL(k_xs_literal<Src>, dim3(1), dim3(64), 0, s, src, count, start, dbg + 1);
+    hipLaunchKernelGGL(k_xs_literal<Src>, dim3(1), dim3(64), 0, s, src, G * rows, start, dbg + 1);
     hipLaunchKernelGGL(k_xs_compare, dim3(1), dim3(1), 0, s, result, dbg + 1, dbg + 1, which);
 #endif
 }

@@ -428,6 +428,40 @@ bool strict_speculative(const cg_ctx *c, const TileGeom &t)
            c->xs.cap_spec >= cg::exact::Workspace::chunks_for(c->count);
 }
 
+// A strict-order dot product over the ranks' row blocks, which follow one another in the reference's index order:
+// every rank forms its approximate sums and, seeded with the approximate totals of the ranks before it (one
+// all-gather), its summaries and its plan -- all ranks at once; only the walks go in turn, the exact accumulator
+// handed from rank to rank by one all-gather of a double per round.  approx(total_out), summaries(seed, nseed) and
+// walk(start_dev, result) enqueue the three phases; *result_at is where the final value is on this rank.
+template <class FA, class FS, class FW>
+int strict_rank_chain(cg_ctx *c, FA approx, FS summaries, FW walk, const double **result_at)
+{
+    hipStream_t s = c->stream;
+    if (c->nranks == 1) {
+        approx((double *)nullptr);
+        summaries((const double *)nullptr, 0);
+        walk((const double *)nullptr, c->strict_slot);
+        HIPCHK(hipGetLastError());
+        *result_at = c->strict_slot;
+        return CG_OK;
+    }
+    double *gb = c->comm->gather_buf();
+    approx(gb + c->rank);
+    HIPCHK(hipGetLastError());
+    CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+    summaries((const double *)gb, c->rank);
+    HIPCHK(hipGetLastError());
+    for (int k = 0; k < c->nranks; ++k) {
+        if (k == c->rank) {
+            walk(k > 0 ? (const double *)(gb + (k - 1)) : (const double *)nullptr, gb + c->rank);
+            HIPCHK(hipGetLastError());
+        }
+        CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+    }
+    *result_at = gb + (c->nranks - 1);
+    return CG_OK;
+}
+
 int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *partials, long npart,
                        int what, double rtol, int have_sub = 0)   // 1: xs.sub holds span sums, linear; 2: by rows
 {
@@ -467,17 +501,26 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
             return CG_OK;
         }
         const bool par = use_parallel_strict(c->strict_impl, c->count);
-        for (int k = 0; k < c->nranks; ++k) {
-            double *slot = c->nranks > 1 ? c->comm->gather_buf() + c->rank : c->strict_slot;
-            const double *seed = k > 0 ? c->comm->gather_buf() + (k - 1) : nullptr;
-            if (k == c->rank) {
-                if (par) cg::exact::enqueue(s, c->xs, v, w, c->count, 0.0, slot, seed, have_sub != 0,
-                                            have_sub == 2 ? c->G : 0, c->rows);   // workspace reserved by cg_solve
-                else hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, seed, slot);
+        if (par) {                                             // workspace reserved by cg_solve
+            const cg::exact::Arrays ar{v, w, c->count, have_sub != 0, have_sub == 2 ? c->G : 0, c->rows};
+            CGCHK(strict_rank_chain(
+                c, [&](double *total) { cg::exact::enqueue_approx(s, c->xs, ar, total); },
+                [&](const double *seed, int nseed) { cg::exact::enqueue_summaries(s, c->xs, ar, 0.0, seed, nseed); },
+                [&](const double *start_dev, double *result) {
+                    cg::exact::enqueue_walk(s, c->xs, ar.src(), ar.count, 0.0, start_dev, result, c->xs.stats);
+                },
+                &src));
+        } else {
+            // the literal replay: the ranks take turns from beginning to end
+            for (int k = 0; k < c->nranks; ++k) {
+                double *slot = c->nranks > 1 ? c->comm->gather_buf() + c->rank : c->strict_slot;
+                const double *seed = k > 0 ? c->comm->gather_buf() + (k - 1) : nullptr;
+                if (k == c->rank)
+                    hipLaunchKernelGGL(cg::k_dot_strict, dim3(1), dim3(64), 0, s, v, w, c->count, 0.0, seed, slot);
+                if (c->nranks > 1) CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
             }
-            if (c->nranks > 1) CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+            src = c->nranks > 1 ? c->comm->gather_buf() + (c->nranks - 1) : c->strict_slot;
         }
-        src = c->nranks > 1 ? c->comm->gather_buf() + (c->nranks - 1) : c->strict_slot;
     } else if (c->multi()) {
         // The kernels of a multi-rank context write their partials straight into this rank's slice of
         // the all-gather buffer (rank_partials); one RCCL all-gather concatenates the ranks' slices in
