@@ -1144,6 +1144,8 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
         if (partials2 != nullptr) {
             sc->qq = s2;
             sc->rho[1] = sane_ratio((sc->tau * sc->tau * s2 - sc->q0) / sc->q0);
+        } else if (count2 < 0) {
+            sc->rho[1] = sane_ratio(sc->beta);          // several ranks: q.q is not known globally; the last ratio will do
         }
     } else if (what == 1 || what == 4) {
         // next iteration's d.q, predicted from the new q0 and the step length of the iteration before this one

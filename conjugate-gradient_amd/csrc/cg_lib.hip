@@ -419,12 +419,12 @@ double *strict_sub(const cg_ctx *c, const TileGeom &t)
     return c->xs.sub;
 }
 
-// Strict order in the lean schedule on one rank: the two passes summarise their products for the sequential sum
+// Strict order in the lean schedule: the two passes summarise their products for the sequential sum
 // while they form them (two hypothesised exponents per span, cg_exact.hpp), instead of storing the products
 // d'*q and reading them and g' once more.  Needs rows that are whole chunks.
 bool strict_speculative(const cg_ctx *c, const TileGeom &t)
 {
-    return c->strict_spec && c->nranks == 1 && strict_sub(c, t) != nullptr && c->G % cg::exact::kChunk == 0 &&
+    return c->strict_spec && strict_sub(c, t) != nullptr && c->G % cg::exact::kChunk == 0 &&
            c->xs.cap_spec >= cg::exact::Workspace::chunks_for(c->count);
 }
 
@@ -476,8 +476,9 @@ int enqueue_dot_finish(cg_ctx *c, const double *v, const double *w, double *part
         // One accumulator over the whole grid in index order.  Row blocks are contiguous
         // in that order, so with several ranks the accumulator is handed from rank to rank:
         // in round k rank k continues from rank k-1's value, and an all-gather of one double
-        // per rank publishes it.  The ranks take turns (this is the parity mode, not the
-        // fast one); every rank ends with the same bits a single rank would compute.
+        // per rank publishes it.  Every rank ends with the same bits a single rank would compute.
+        // Only the ordered walks take turns; what they walk over is prepared on all ranks at once
+        // (strict_rank_chain).
         if (c->strict_blocks > 1) {
             // The reference's own multi-rank layout on this one GPU: rank r = ci*s + cj of its s x s
             // decomposition sums the products of its (G/s)^2 block sequentially in local row-wise
@@ -634,10 +635,21 @@ int enqueue_lean_iteration(cg_ctx *c)
         cg::exact::SrcStencil src;
         src.d = c->d[in]; src.g = c->g; src.sc = c->sc; src.coef = c->coef;
         src.G = c->G; src.rows = c->rows; src.row0 = c->row0; src.count = c->count; src.beta = 0.0;
-        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, c->strict_slot, c->strict_audit != 0);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_dq, tq.ntiles, c->strict_slot, 1, c->sc, 0, 0.0,
-                           c->hist, c->hist_cap, (const double *)a.partials2, tq.ntiles);
+        const double *at = nullptr;
+        CGCHK(strict_rank_chain(
+            c, [&](double *total) { cg::exact::spec_approx(s, c->xs, c->G, c->rows, total); },
+            [&](const double *seed, int nseed) {
+                cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, seed, nseed);
+            },
+            [&](const double *start_dev, double *result) {
+                cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats);
+                if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
+            },
+            &at));
+        // (the growth prediction for g.g needs q.q of the whole grid: one rank has it, several fall back on beta)
+        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_dq, tq.ntiles, at, 1, c->sc, 0, 0.0,
+                           c->hist, c->hist_cap, c->nranks == 1 ? (const double *)a.partials2 : (const double *)nullptr,
+                           c->nranks == 1 ? tq.ntiles : -1L);
     } else {
         if (strict) {
             a.q = c->q; a.store_products = 1;
@@ -686,9 +698,18 @@ int enqueue_lean_iteration(cg_ctx *c)
     if (spec) {
         const int vec = ((reinterpret_cast<uintptr_t>(b.g_out)) & 15) == 0 ? 1 : 0;
         const cg::exact::SrcArrays src{b.g_out, b.g_out, c->count, vec};
-        cg::exact::enqueue_spec(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, c->strict_slot, c->strict_audit != 0);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_gg, n_gg, c->strict_slot, 1, c->sc, with_u ? 1 : 4, 0.0,
+        const double *at = nullptr;
+        CGCHK(strict_rank_chain(
+            c, [&](double *total) { cg::exact::spec_approx(s, c->xs, c->G, c->rows, total); },
+            [&](const double *seed, int nseed) {
+                cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, seed, nseed);
+            },
+            [&](const double *start_dev, double *result) {
+                cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats + 8);
+                if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
+            },
+            &at));
+        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_gg, n_gg, at, 1, c->sc, with_u ? 1 : 4, 0.0,
                            c->hist, c->hist_cap);
     } else {
         CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
@@ -1536,7 +1557,7 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         const long before = c->xs.cap_chunks;
         HIPCHK(c->xs.reserve(c->count));
         if (c->xs.cap_chunks != before) drop_graph(c);      // captured nodes hold the old workspace
-        if (c->strict_spec && c->nranks == 1 && c->effective_schedule() == CG_SCHED_LEAN && c->G % cg::exact::kChunk == 0 &&
+        if (c->strict_spec && c->effective_schedule() == CG_SCHED_LEAN && c->G % cg::exact::kChunk == 0 &&
             c->xs.cap_spec < cg::exact::Workspace::chunks_for(c->count)) {
             HIPCHK(c->xs.reserve_spec(c->count));
             drop_graph(c);
@@ -1726,7 +1747,7 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     // no solve or read-back until cg_init_problem has set the problem up again.
     c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->needs_init = true;
     bool spec = false;
-    if (sched == CG_SCHED_LEAN && c->reduce == CG_REDUCE_STRICT && c->strict_spec && c->nranks == 1 &&
+    if (sched == CG_SCHED_LEAN && c->reduce == CG_REDUCE_STRICT && c->strict_spec &&
         c->G % cg::exact::kChunk == 0 && use_parallel_strict(c->strict_impl, c->count)) {
         HIPCHK(c->xs.reserve(c->count));
         HIPCHK(c->xs.reserve_spec(c->count));

@@ -167,7 +167,7 @@ typedef struct cg_ctx cg_ctx;
                                   utils.c:408-417), the s*s sums combined as MPICH's MPI_Allreduce combines
                                   them (utils.c:380) -- and so reproduces the bits of `mpirun -np s*s ./cg`.
                                   0 or 1 = the single-rank order (default) */
-#define CG_OPT_STRICT_SPEC 15  /* strict order, lean schedule, one rank, rows of a multiple of 1024 points: 1 (default) =
+#define CG_OPT_STRICT_SPEC 15  /* strict order, lean schedule, rows of a multiple of 1024 points: 1 (default) =
                                   the passes summarise their products for the sequential sum while they form them, under
                                   two hypothesised exponents per span (from the previous iteration's prefix sums); spans
                                   whose hypotheses miss are redone.  0 = store the products and read them again.  Same bits. */

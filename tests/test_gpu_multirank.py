@@ -53,7 +53,8 @@ def test_multirank_stop_rule(oracle, tmp_path):
 @pytest.mark.parametrize("order", ["strict_replay", "strict_parallel"])
 @pytest.mark.parametrize("schedule,world,n,iters", [("classic", 2, 63, 50), ("fused", 4, 63, 50), ("fused", 4, 255, 200),
                                                     ("classic", 4, 1023, 40), ("fused", 2, 1023, 200),
-                                                    ("lean", 4, 255, 200), ("lean", 2, 1023, 61), ("fused_noq", 4, 63, 50)])
+                                                    ("lean", 4, 255, 200), ("lean", 2, 1023, 61), ("fused_noq", 4, 63, 50),
+                                                    ("lean", 4, 1023, 120), ("lean", 8, 2047, 24)])
 def test_multirank_strict_order_reproduces_single_rank_reference_bits(golden, oracle, tmp_path, order, schedule, world, n, iters):
     # The accumulator of every dot product is handed from rank to rank, so 2 or 4 row blocks give the
     # bits the reference gives on ONE rank (its own np=4 run differs from its np=1 run by ~1e-9).
