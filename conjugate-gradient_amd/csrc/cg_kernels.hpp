@@ -119,21 +119,6 @@ __device__ __forceinline__ double block_sum(double v, double *wave_slots)
     return s;
 }
 
-// The same for a float (one data-parallel move and one add per step).
-__device__ __forceinline__ float wave_sum_unordered_f32(float v)
-{
-#define CG_DPP_ADDF(CTRL, ROW_MASK)                                                                        \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true))
-    CG_DPP_ADDF(0x111, 0xf);
-    CG_DPP_ADDF(0x112, 0xf);
-    CG_DPP_ADDF(0x114, 0xf);
-    CG_DPP_ADDF(0x118, 0xf);
-    CG_DPP_ADDF(0x142, 0xa);
-    CG_DPP_ADDF(0x143, 0xc);
-#undef CG_DPP_ADDF
-    return v;
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter (s_waitcnt vmcnt(0)), which would retire every prefetched
 // global load at each row step and serialise the kernel on HBM latency; here the
@@ -404,26 +389,6 @@ __device__ __forceinline__ SpanEntry span_entry(const double (&p)[VEC], int e0, 
         s.D1 += r1;
     }
     return s;
-}
-
-// The same sums for ONE row by data-parallel reductions inside the wavefront (result in lane 63, which stores).
-// Called for several buffered rows in a row, so that their dependent reduction chains interleave.
-template <bool NONNEG>
-__device__ __forceinline__ void span_reduce_store(const SpanEntry &e, bool tie0, bool tie1, long m, bool store,
-                                                  long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
-{
-    const double su = wave_sum_unordered(e.sub);
-    double d0 = wave_sum_unordered(e.D0), d1 = wave_sum_unordered(e.D1);
-    float qf = 0.0f;
-    if (!NONNEG) qf = wave_sum_unordered_f32(e.qf);
-    if (__ballot(tie0) != 0ull) d0 = __builtin_nan("");
-    if (__ballot(tie1) != 0ull) d1 = __builtin_nan("");
-    if (store && (threadIdx.x & 63) == 63) {
-        sub[span_col + m] = su;
-        spD0[span_col + m] = d0;
-        spD1[span_col + m] = d1;
-        if (!NONNEG) spQ0[span_col + m] = (double)qf * (1.0 + 0x1p-12) + 1.0;
-    }
 }
 
 // ---- eight rows at once -----------------------------------------------------------------------------------
@@ -729,6 +694,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     // NH > 0: the span sums of a batch of four or eight rows are reduced over the wavefront together (span4_push,
     // span8_push); a kernel that keeps fewer than four rows in flight goes through its ring twice or four times per batch.
     constexpr int BATCH = (NH > 0 && PF < 4) ? 4 : PF;
+    static_assert(NH == 0 || BATCH == 4 || BATCH == 8, "the span sums are reduced in batches of four or eight rows");
     for (int rb = r0 - 1; rb <= r1; rb += BATCH) {
         Span8 span8;
 #pragma unroll
@@ -830,12 +796,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                     } else {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                        if (BATCH == 4)
-                            span4_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                        else if (BATCH == 8)
-                            span8_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                        else
-                            span_reduce_store<true>(e, t0, t1, m, row_own, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        if (BATCH == 8) span8_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        else span4_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                     }
                 }
                 if (MODE == 5) {
@@ -860,15 +822,11 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                     if (NH == 0) {
                         span = wave_sum_unordered(span);
                         if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
-                    } else if (BATCH == 8 || BATCH == 4) {
+                    } else {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
                         if (BATCH == 8) span8_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                         else span4_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                    } else {
-                        bool t0, t1;
-                        const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                        span_reduce_store<false>(e, t0, t1, m, row_own, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                     }
                 }
                 if (WRITE_Q) {

@@ -146,6 +146,14 @@ struct TileGeom {
     long max_wgs = 0; // > 0: at most this many workgroups per launch, each walking several tiles
 };
 
+// The tiled kernel addresses a tile's rows (and its two halo rows) through one buffer descriptor with 32-bit byte
+// offsets, and masks lanes off with an offset of 0x7fffff00: a tile must stay below that many bytes.
+long max_tile_rows(long G)
+{
+    const long fit = 0x7ff00000L / (G * 8) - 2;
+    return fit < 1 ? 1 : fit;
+}
+
 TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
 {
     TileGeom t;
@@ -170,9 +178,7 @@ TileGeom tile_geom(long G, long rows, bool all_aligned, long tile_h_opt)
         if (h < 16) h = 16;
         t.max_wgs = (long)t.nstrips * per_strip;
     }
-    // the kernel addresses a tile's rows (and its two halo rows) through one buffer descriptor with 32-bit offsets
-    const long fit = 0x7ff00000L / (G * 8) - 2;
-    if (h > fit) h = fit;
+    if (h > max_tile_rows(G)) h = max_tile_rows(G);
     if (h > rows) h = rows;
     if (h < 1) h = 1;
     t.tile_h = (int)h;
@@ -362,6 +368,7 @@ TileGeom dq_geom(const cg_ctx *c, TileGeom t)
         long h = (c->rows + 2 * per_strip - 1) / (2 * per_strip);
         if (h < 32) h = (c->rows + per_strip - 1) / per_strip;
         if (h < 16) h = 16;
+        if (h > max_tile_rows(c->G)) h = max_tile_rows(c->G);
         if (h > c->rows) h = c->rows;
         t.tile_h = (int)h;
         t.ntiles = (long)t.nstrips * ((c->rows + h - 1) / h);
