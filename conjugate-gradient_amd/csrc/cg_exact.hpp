@@ -118,7 +118,9 @@ __device__ __forceinline__ int exponent_of(double s)
 // The per-element validity tests are folded into two running maxima and checked once:
 // |x| < 2^51 for every addend <=> max|x| < 2^51; no tie <=> max|x - rint(x)| != 0.5 (it never
 // exceeds 0.5); a NaN addend poisons D (v_max would skip it), which the final D == D catches.
-__device__ __forceinline__ Summary piece_summary(const double (&p)[kPerLane], int e)
+// any_size: accept addends of any magnitude (the self-check recomputes summaries that were certified another way,
+// by the sum of the magnitudes staying below 2^52).
+__device__ __forceinline__ Summary piece_summary(const double (&p)[kPerLane], int e, bool any_size = false)
 {
     const int sh = (e == kNoExp) ? 0 : 52 - e;
     Summary s = identity();
@@ -136,7 +138,7 @@ __device__ __forceinline__ Summary piece_summary(const double (&p)[kPerLane], in
     }
     const bool nan = !(s.D == s.D) || !(pmax == pmax);
     if (!nan && pmax == 0.0) return identity();     // adding zeros leaves a non-zero accumulator unchanged
-    s.bad = (nan || !(amax < 0x1p51) || fmaxv == 0.5 || e == kNoExp) ? 1 : 0;
+    s.bad = (nan || !(any_size || amax < 0x1p51) || fmaxv == 0.5 || e == kNoExp) ? 1 : 0;
     s.e = e;
     return s;
 }
@@ -1168,15 +1170,26 @@ __global__ __launch_bounds__(256) void k_xs_audit(const Src src_in, long count, 
         const long lo = c * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
         double p[kPerLane];
         src.chunk16(lo, hi, lane, T[wv], p);
-        Summary t = wave_compose_same_e(piece_summary(p, st.e), st.e);
+        Summary t = wave_compose_same_e(piece_summary(p, st.e, true), st.e);
         t.D = __shfl(t.D, 0, 64); t.mn = __shfl(t.mn, 0, 64); t.mx = __shfl(t.mx, 0, 64); t.bad = __shfl(t.bad, 0, 64);
-        if (lane == 0 && (t.bad || t.D != st.D || t.mn < st.mn || t.mx > st.mx)) atomicAdd(fails, 1ull);
+        if (lane == 0 && (t.bad || t.D != st.D || t.mn < st.mn || t.mx > st.mx)) {
+            atomicAdd(fails, 1ull);
+#ifdef CG_DEBUG_XS
+            printf("audit: chunk %ld e %d: stored D %a mn %a mx %a | true D %a mn %a mx %a bad %d\n", c, st.e, st.D, st.mn, st.mx,
+                   t.D, t.mn, t.mx, t.bad);
+#endif
+        }
     }
 }
 __global__ void k_xs_audit_result(const double *plan, const double *hier, unsigned long long *fails)
 {
     const double a = *plan, b = *hier;
-    if (!(a == b || (a != a && b != b))) atomicAdd(fails, 1ull);
+    if (!(a == b || (a != a && b != b))) {
+        atomicAdd(fails, 1ull);
+#ifdef CG_DEBUG_XS
+        printf("audit: plan-driven walk %a, hierarchical walk %a\n", a, b);
+#endif
+    }
 }
 
 #ifdef CG_DEBUG_XS

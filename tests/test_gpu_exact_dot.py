@@ -147,18 +147,26 @@ def test_strict_solve_matches_reference_at_speed(cg, oracle, golden, n, iters):
     assert float(seq_sum(oracle, s.vector(cg.VEC_U))).hex() == rec["sum_u_hex"]
 
 
-@pytest.mark.parametrize("n,iters", [(1023, 120), (2047, 40), (4095, 24)])
-def test_strict_summaries_pass_the_self_check(cg, n, iters):
+@pytest.mark.parametrize("n,iters,coef", [(1023, 120, None), (2047, 40, None), (4095, 24, None),
+                                          (2047, 40, (-1, -2, -1, -2, 12, -2, -1, -2, -1)),      # all nine entries
+                                          (1023, 80, (0, -3, 0, -1, 8, -1, 0, -3, 0))])
+def test_strict_summaries_pass_the_self_check(cg, n, iters, coef):
     # Every chunk summary the passes hand over (sums under the hypothesised binade, bounds of the running value)
     # is compared with one recomputed from the products, after every dot product of the solve, and the
     # plan-driven walk with the plain hierarchical one; the history must equal the literal replay's.
-    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT).init_problem()
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT)
+    if coef is not None:
+        s.set_stencil(coef)
+    s.init_problem()
     s.set_option(cg.lib.OPT_STRICT_AUDIT, 1)
     s.solve(iters)
     assert s.get_option(cg.lib.OPT_STRICT_AUDIT) == 0
     got = s.history(iters)
     s.close()
-    lit = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_impl=cg.STRICT_REPLAY).init_problem()
+    lit = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_impl=cg.STRICT_REPLAY)
+    if coef is not None:
+        lit.set_stencil(coef)
+    lit.init_problem()
     lit.solve(iters)
     want = lit.history(iters)
     lit.close()
