@@ -28,6 +28,15 @@
 //      group, then to 16-element pieces of the failing chunk (summarised on the spot
 //      under the accumulator's actual exponent), and finally to the literal
 //      element-by-element recurrence for the one piece that does not fit.
+//   E. that wavefront spends its time waiting unless everything it will need is laid out for it
+//      beforehand.  The approximate prefix sums also say WHERE the walk will have to descend (where
+//      the accumulator changes its binade), so the marked chunks are listed in order, their
+//      products and the summaries of their 16-element pieces (under the three binades around the
+//      predicted one, in prefix form) are staged, and each stretch between two marked chunks is
+//      composed into ONE summary: the walk applies a stretch in one step, takes the marked chunk
+//      apart with what was staged, and has the next two entries in flight (k_xs_plan, k_xs_walk).
+//      A plan that turns out wrong costs time, never a bit: every summary is judged by the true
+//      accumulator, and the walk falls back to the hierarchical descent of D.
 // Failures are rare: each binade crossing of the accumulator (a few dozen per dot
 // product), the leading zeros, and ties (~2^-29 per element).  The margins of one ulp
 // at both ends of the binade make the integer model exact: a running value of at
