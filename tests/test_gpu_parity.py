@@ -214,9 +214,8 @@ def test_schedules_agree_bitwise_given_the_same_scalars(cg):
         assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1])
 
 
-@pytest.mark.parametrize("mode", ["strict", "fast"])
-def test_stop_rule(cg, oracle, golden, mode):
-    n = 63
+@pytest.mark.parametrize("mode,n", [("strict", 63), ("fast", 63), ("strict", 1023)])   # 1023: span sums formed in the passes
+def test_stop_rule(cg, oracle, golden, mode, n):
     rec = golden[(n, 10000, 1, 1e-8)]
     s = cg.CGSolver(n)
     s.configure(reduce=cg.REDUCE_STRICT if mode == "strict" else cg.REDUCE_FAST, graph_iters=10).init_problem()
