@@ -139,6 +139,7 @@ struct TileGeom {
     int pf_mode[6] = {4, 4, 4, 4, 4, 4};   // ... per kernel mode (solver context)
     int pf_spec_read = 4;                  // ... of the read-only pass when it also forms the strict-order span sums
     int wg_mult = 2;                       // workgroups per CU of the read-only pass
+    bool plain_order = false;              // the read-only pass takes its tiles in plain order (no XCD-aware placement)
     int vec;          // 2 when rows are 16-byte aligned (even G), else 1
     int nstrips;
     int tile_h;
@@ -202,6 +203,7 @@ long launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
     a.ntiles_launch = nrt * t.nstrips;
     // The read-only pass gets two workgroups per CU: measured 6.6 TB/s against 5.6 with one.
     const long cap = (MODE == 3) ? t.wg_mult * t.max_wgs : t.max_wgs;
+    if (MODE == 3 && t.plain_order) a.remap = 0;
     const long nwg = (cap > 0 && cap < a.ntiles_launch) ? cap : a.ntiles_launch;
     const dim3 grid((unsigned)nwg), block(kBlock);
 #define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C, NH>), grid, block, 0, s, a)
@@ -361,12 +363,20 @@ bool strict_speculative(const cg_ctx *c, const TileGeom &t);
 
 TileGeom dq_geom(const cg_ctx *c, TileGeom t)
 {
-    // Strict order with span sums formed in the pass: three workgroups per CU, each walking two tiles.
+    // Strict order with span sums formed in the pass: three workgroups per CU.  That pass is bound by its
+    // instruction stream, not by memory, and wants another geometry than the others -- measured at 16384^2:
+    // tiles of 256 rows taken in plain order 0.90 ms, the same with the XCD-aware placement 1.00 ms (tiles of 512
+    // rows: 1.20 ms), two tiles of 342 rows per workgroup 0.93 ms either way.  Blocks too small for two rounds of
+    // 256-row tiles get one or two tiles per workgroup.
     if (c->tile_h == 0 && t.max_wgs > 0 && c->reduce == CG_REDUCE_STRICT && t.pf_spec_read <= 2 && strict_speculative(c, t)) {
         long per_strip = 3 * t.max_wgs / t.nstrips;
         if (per_strip < 1) per_strip = 1;
-        long h = (c->rows + 2 * per_strip - 1) / (2 * per_strip);
-        if (h < 32) h = (c->rows + per_strip - 1) / per_strip;
+        long h = 256;
+        if ((long)t.nstrips * ((c->rows + h - 1) / h) < 6 * t.max_wgs) {
+            h = (c->rows + 2 * per_strip - 1) / (2 * per_strip);
+            if (h < 32) h = (c->rows + per_strip - 1) / per_strip;
+        }
+        t.plain_order = true;
         if (h < 16) h = 16;
         if (h > max_tile_rows(c->G)) h = max_tile_rows(c->G);
         if (h > c->rows) h = c->rows;
