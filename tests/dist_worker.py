@@ -1,6 +1,8 @@
 """One rank of a multi-process row-block solve (started by test_dist_gloo.py / test_gpu_multirank.py).
 
-  python dist_worker.py <mode> <n> <iters> <outdir> [schedule] [rtol] [strict|strict_replay|strict_parallel]
+  python dist_worker.py <mode> <n> <iters> <outdir> [schedule] [rtol] [strict|strict_replay|strict_parallel] [digest]
+
+"digest" stores the SHA-256 of each vector's bytes instead of the vector (grids too large to write out).
 
 mode "oracle": the compute is the CPU oracle (checker code), the communication is the product's
                RowTransport over gloo -- this pins the transport's semantics without a GPU.
@@ -8,6 +10,7 @@ mode "gpu":    the compute is the HIP library (one context per rank, all ranks o
                and partial sums travel through the same RowTransport via cg_comm_init_host.
 Rank/world/rendezvous come from RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT.
 """
+import hashlib
 import importlib
 import os
 import sys
@@ -57,7 +60,7 @@ def oracle_rank(tr, dist_mod, n, iters, order):
     return dict(u=u, g=g, d=d, hist=np.array(hist), row0=row0)
 
 
-def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast"):
+def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast", digest=False):
     G = n + 1
     row0, rows = cg.dist.partition(G, tr.world, tr.rank)
     s = cg.CGSolver(n, device=0, row0=row0, rows=rows, rank=tr.rank, nranks=tr.world)
@@ -78,8 +81,10 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast"):
         h1 = s.history(iters)
         r = s.solve(iters - iters // 2)
         total, hist, q_init = first.iters + r.iters, np.concatenate([h1, s.history(iters)]), first.q_init
-    out = dict(u=s.vector(cg.VEC_U), g=s.vector(cg.VEC_G), d=s.vector(cg.VEC_D), row0=row0, hist=hist,
-               q1=r.q1, iters=total, converged=int(r.converged), q_init=q_init)
+    out = dict(row0=row0, hist=hist, q1=r.q1, iters=total, converged=int(r.converged), q_init=q_init)
+    for key, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+        v = s.vector(which)
+        out[key] = np.array(hashlib.sha256(v).hexdigest()) if digest else v
     s.close()
     return out
 
@@ -97,7 +102,7 @@ def main():
         res = oracle_rank(tr, cg.dist, n, iters, extra[0] if extra else "chained")
     else:
         res = gpu_rank(tr, cg, n, iters, extra[0] if extra else "fused_noq", float(extra[1]) if len(extra) > 1 else 0.0,
-                       extra[2] if len(extra) > 2 else "fast")
+                       extra[2] if len(extra) > 2 else "fast", len(extra) > 3 and extra[3] == "digest")
     np.savez(os.path.join(outdir, f"rank{tr.rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()

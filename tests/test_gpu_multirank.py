@@ -70,6 +70,39 @@ def test_multirank_strict_order_reproduces_single_rank_reference_bits(golden, or
     assert np.array_equal(np.asarray(res[0]["hist"]).view(np.uint64), ref["hist"].view(np.uint64))
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_headline_grid_in_row_blocks_reproduces_the_single_rank_bits(cg, tmp_path, world):
+    # 16384^2 split over 2 and 8 row blocks (8: the 2048-row blocks of an 8-GPU node), strict order: every block
+    # must hold exactly the bits of the single-rank solve, whose 1000-iteration result the reference's own run pins.
+    import hashlib
+    n, iters = 16383, 24
+    res = run_ranks(world, ["gpu", n, iters, tmp_path, "lean", 0.0, "strict", "digest"], tmp_path, timeout=600)
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT).init_problem()
+    s.solve(iters // 2)
+    r = s.solve(iters - iters // 2)
+    assert all(int(x["iters"]) == iters for x in res)
+    assert all(float(x["q1"]).hex() == float(r.q1).hex() for x in res)
+    rows = (n + 1) // world
+    for key, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+        v = s.vector(which)
+        for x in res:
+            r0 = int(x["row0"])
+            assert str(x[key]) == hashlib.sha256(v[r0:r0 + rows]).hexdigest(), (key, r0)
+    s.close()
+
+
+def test_headline_grid_in_row_blocks_fast_order(cg, tmp_path):
+    # the same grid over 4 blocks in the fast order: another (fixed) order of the partial sums, same solve
+    n, iters = 16383, 24
+    res = run_ranks(4, ["gpu", n, iters, tmp_path, "lean", 0.0, "fast", "digest"], tmp_path, timeout=600)
+    s = cg.CGSolver(n).init_problem()
+    s.solve(iters // 2)
+    r = s.solve(iters - iters // 2)
+    assert len({float(x["q1"]).hex() for x in res}) == 1
+    assert abs(float(res[0]["q1"]) - r.q1) <= 1e-9 * r.q1
+    s.close()
+
+
 def test_rccl_calls_on_a_single_rank_communicator(cg):
     # One GPU cannot host two RCCL ranks, but a one-rank communicator still runs the library's
     # dlopen of librccl, ncclCommInitRank, ncclAllGather and a grouped ncclSend/ncclRecv (to itself).
