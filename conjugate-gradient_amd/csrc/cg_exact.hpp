@@ -772,7 +772,25 @@ struct Pieces {
     int flags;                                        // bit h: this piece is unusable under hypothesis h; bit 4+h: hypothesis h is not prepared
 };
 constexpr int kPieceDoubles = 10;                     // per lane: 3 x (P, lo, hi) and the flags
-constexpr int kEntry = kChunk + 64 * kPieceDoubles + 4;   // doubles per entry of the plan: products, pieces, a stretch summary
+constexpr int kEntry = kChunk + 64 * kPieceDoubles;   // doubles per entry of the plan: products, pieces
+
+// What the walk needs of an entry when nothing unforeseen happens, 36 doubles that every lane loads alike: with the
+// accumulator as close to the approximate prefix sum as it always is, the pieces of a marked chunk fall into a run
+// that certainly applies under the predicted binade e_g (pieces [0, f)), ONE piece f that may leave the binade (or
+// holds a tie), and a run behind it that certainly applies under whichever of e_g - 1, e_g, e_g + 1 the accumulator
+// then has.  The plan composes the two runs into summaries and copies piece f's products, so the walk's work per
+// marked chunk is three range tests on wave-uniform values and sixteen additions: no ballot, no lane reads.  The walk
+// still judges every summary by the TRUE accumulator, and takes the chunk apart the general way (refine) if any
+// test fails.
+//   [0..2] D, mn, mx of pieces [0, f) under e_g   [3] low word: f | flags << 8
+//   [4..19] the products of piece f                [20..28] D, mn, mx of pieces (f, 64) under e_g - 1, e_g, e_g + 1
+//   [32..35] the summary of the stretch of chunks before the entry's chunk (D, mn, mx, bad / e)
+constexpr int kBrief = 36;
+constexpr int kBriefNoFast = 1;        // flags: the runs are not prepared (no usable e_g, ragged chunk, huge sums)
+constexpr int kBriefAfterBad = 2;      // << h: the run behind piece f is unusable under hypothesis h
+constexpr int kBriefNoBefore = 16;     // f == 0
+constexpr int kBriefNoAfter = 32;      // f >= 63
+constexpr int kBriefNoPiece = 64;      // f == 64: every piece applies under e_g
 
 __device__ __forceinline__ double read_lane(double v, int l)        // l wave-uniform
 {
@@ -862,6 +880,19 @@ __device__ __forceinline__ double refine(const double (&p)[kPerLane], const Piec
     return s;
 }
 
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 // Ordered composition of summaries arr[lo .. hi) by one wavefront (result in every lane).
 __device__ __forceinline__ Summary range_compose(const Summary *__restrict__ arr, long lo, long hi, int lane)
 {
@@ -949,11 +980,12 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
     for (int item = blockIdx.x * 4 + wv; item <= 2 * n; item += gridDim.x * 4) {
         const int k = (item <= n) ? item : item - n - 1;
         double *ent = dump + (long)k * kEntry;
+        double *brief = dump + (long)(kPlanCap + 1) * kEntry + (long)k * kBrief;
         if (item <= n) {
             const long from = (k == 0) ? 0 : (long)clist[k - 1] + 1, to = (k < n) ? (long)clist[k] : nchunks;
             const Summary st = stretch_summary(chunks, groups, supers, from, to, lane);
             if (lane == 0) {
-                xv2 *ps = reinterpret_cast<xv2 *>(ent + kChunk + 64 * kPieceDoubles);
+                xv2 *ps = reinterpret_cast<xv2 *>(brief + 32);
                 xv2 v0, v1;
                 v0.x = st.D; v0.y = st.mn; v1.x = st.mx; v1.y = __hiloint2double(st.bad & 1, st.e);
                 ps[0] = v0; ps[1] = v1;
@@ -969,6 +1001,10 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
         for (int i = 0; i < kPerLane / 2; ++i) { xv2 v; v.x = p[2 * i]; v.y = p[2 * i + 1]; dst[i] = v; }
         const int e_g = exponent_of(goff[c / kGroup] + approx[c]);
         if (lane == 0) pexp[k] = e_g;
+        double bf[30];                                   // the brief (wave-uniform values)
+#pragma unroll
+        for (int i = 0; i < 30; ++i) bf[i] = 0.0;
+        int f = 0, bflags = kBriefNoFast;
         if (e_g != kNoExp) {
             double out[kPieceDoubles];
             int flags = 0;
@@ -994,16 +1030,50 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
             xv2 *pd = reinterpret_cast<xv2 *>(ent + kChunk + lane * kPieceDoubles);
 #pragma unroll
             for (int i = 0; i < kPieceDoubles / 2; ++i) { xv2 v; v.x = out[2 * i]; v.y = out[2 * i + 1]; pd[i] = v; }
+            // The brief: which pieces certainly apply, given how close to the approximation the accumulator will be.
+            const double A = goff[c / kGroup] + approx[c];
+            const double Ag = ldexp(A, 52 - e_g);
+            const double lo_m = Ag + out[4] - kPlanMargin, hi_m = Ag + out[5] + kPlanMargin;
+            const bool certain = !(flags & 2) && ((A > 0.0) ? (lo_m >= 0x1p52 + 1.0) && (hi_m <= 0x1p53 - 1.0)
+                                                            : (hi_m <= -(0x1p52 + 1.0)) && (lo_m >= -(0x1p53 - 1.0)));
+            const unsigned long long unsure = ~__ballot(certain);
+            f = unsure ? (int)__builtin_ctzll(unsure) : 64;
+            bflags = ((flags & (16 << 1)) || hi - lo < kChunk) ? kBriefNoFast : 0;
+            if (f == 0) bflags |= kBriefNoBefore;
+            if (f >= 63) bflags |= kBriefNoAfter;
+            if (f == 64) bflags |= kBriefNoPiece;
+            if (f > 0) {
+                bf[0] = read_lane(out[3], f - 1);
+                bf[1] = wave_min(lane < f ? out[4] : HUGE_VAL);
+                bf[2] = wave_max(lane < f ? out[5] : -HUGE_VAL);
+            }
+            if (f < 64) {
+#pragma unroll
+                for (int i = 0; i < kPerLane; ++i) bf[4 + i] = read_lane(p[i], f);
+            }
+            if (f < 63) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const double base = read_lane(out[3 * h], f);
+                    bf[20 + 3 * h] = read_lane(out[3 * h], 63) - base;
+                    bf[21 + 3 * h] = wave_min(lane > f ? out[3 * h + 1] : HUGE_VAL) - base;
+                    bf[22 + 3 * h] = wave_max(lane > f ? out[3 * h + 2] : -HUGE_VAL) - base;
+                    if (__ballot(lane > f && ((flags >> h) & 1)) != 0ull || (flags & (16 << h))) bflags |= kBriefAfterBad << h;
+                }
+            }
+        }
+        bf[3] = __hiloint2double(0, f | (bflags << 8));
+        if (lane < 15) {                                  // lane i stores doubles 2i, 2i + 1
+            xv2 v;
+            v.x = bf[0]; v.y = bf[1];
+#pragma unroll
+            for (int i = 1; i < 15; ++i) if (lane == i) { v.x = bf[2 * i]; v.y = bf[2 * i + 1]; }
+            reinterpret_cast<xv2 *>(brief)[lane] = v;
         }
     }
 }
 
-// What the walk holds of one entry of the plan.
-struct Entry {
-    xv2 p[kPerLane / 2];                              // the chunk's products
-    xv2 q[kPieceDoubles / 2];                         // its prepared pieces
-    xv2 st[2];                                        // the stretch before it
-};
+constexpr int kBriefBatch = 64;                      // briefs the walk keeps in LDS at a time
 
 // The hierarchical walk over the chunks [a, b), without a plan: group summaries 64 at a time where whole groups
 // lie ahead, the chunks of a group that does not apply (or is only partly inside the range), the elements of a
@@ -1049,12 +1119,13 @@ __device__ __forceinline__ double walk_range(const Src &src, long count, const S
 // The ordered walk, one wavefront -- so nothing hides a wait, and everything it will need is laid out for it
 // beforehand by the plan (plist / pexp / pn / dump; plist may be null: then the whole range is walked
 // hierarchically).  Per entry of the plan: the stretch of chunks before the entry's chunk is applied in one step if
-// its summary holds for the true accumulator (walked hierarchically otherwise), then the chunk is taken apart
-// with its staged products and prepared pieces (taking apart a chunk that would have applied after all costs one
-// scan of its pieces and is as exact as everything else).  The next two entries are always on their way.
+// its summary holds for the true accumulator (walked hierarchically otherwise), then the chunk is taken apart: by
+// its brief (two prepared runs of pieces around one piece added literally) if the brief's tests hold for the true
+// accumulator, else with its staged products and prepared pieces, fetched then (taking apart a chunk that would
+// have applied after all costs a few tests and is as exact as everything else).
 // stats (may be null): [0] stretches walked hierarchically plus groups descended into, [1] chunks taken apart,
 // [2] rounds of piece summaries inside them, [3] pieces replayed without summarising, [4] chunks taken apart
-// according to the plan.
+// according to the plan, [5] those of them whose brief did not hold.
 template <class Src>
 __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                                                 const Summary *__restrict__ chunks, long nchunks,
@@ -1065,98 +1136,132 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
 {
     __shared__ __attribute__((aligned(16))) double T[Src::kLds];
     __shared__ int lst[kPlanCap], lexp[kPlanCap];
+    __shared__ __attribute__((aligned(16))) double lbrief[kBriefBatch * kBrief];
     Src src = src_in;
     src.prepare();
     const int lane = threadIdx.x;
     double s = (start_dev != nullptr) ? *start_dev : start;
-    long n_groups = 0, n_chunks = 0, n_planned = 0, tally[2] = {0, 0};
+    long n_groups = 0, n_chunks = 0, n_planned = 0, n_general = 0, tally[2] = {0, 0};
 #ifdef CG_WALK_CLOCKS
-    long clk_ref = 0, clk_st = 0, clk_all = clock64();
+    long clk_all = clock64();
 #endif
     if (plist == nullptr) {
         s = walk_range(src, count, chunks, nchunks, groups, 0, nchunks, s, lane, T, n_groups, n_chunks, tally);
     } else {
         int n = uniform(*pn);
         if (n > kPlanCap) n = kPlanCap;
-        for (int k = lane; k < n; k += 64) { lst[k] = plist[k]; lexp[k] = pexp[k]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        Entry ent[2];                                  // entries k and k + 1, alternating (no copies: the loop runs in pairs)
-        auto fetch_entry = [&](int k, Entry &e) {      // loads only; nothing waits for them here
-            if (k > n) return;
-            const double *base = dump + (long)k * kEntry;
-            const xv2 *fs = reinterpret_cast<const xv2 *>(base + kChunk + 64 * kPieceDoubles);
-            e.st[0] = fs[0]; e.st[1] = fs[1];
-            if (k == n) return;
-            const xv2 *from = reinterpret_cast<const xv2 *>(base + lane * kPerLane);
+        const double *briefs = dump + (long)(kPlanCap + 1) * kEntry;
+        // Briefs travel 64 at a time: lane-strided 16-byte loads into registers (the next batch is fetched while
+        // this one is walked), then into LDS, where the walk reads them at wave-uniform addresses.
+        constexpr int kPer = kBriefBatch * kBrief / 2 / 64;        // 16-byte pieces per lane and batch
+        xv2 stage[kPer] = {};
+        auto fetch_batch = [&](int first) {
+            if (first > n) return;
+            const xv2 *from = reinterpret_cast<const xv2 *>(briefs + (long)first * kBrief);
+            const int have = ((n + 1 - first < kBriefBatch) ? n + 1 - first : kBriefBatch) * (kBrief / 2);
 #pragma unroll
-            for (int i = 0; i < kPerLane / 2; ++i) e.p[i] = from[i];
-            const xv2 *fq = reinterpret_cast<const xv2 *>(base + kChunk + lane * kPieceDoubles);
-#pragma unroll
-            for (int i = 0; i < kPieceDoubles / 2; ++i) e.q[i] = fq[i];
+            for (int i = 0; i < kPer; ++i)
+                if (i * 64 + lane < have) stage[i] = from[i * 64 + lane];
         };
+        auto store_batch = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the last batch has been read
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) reinterpret_cast<xv2 *>(lbrief)[i * 64 + lane] = stage[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        fetch_batch(0);
+        for (int k = lane; k < n; k += 64) { lst[k] = plist[k]; lexp[k] = pexp[k]; }
         long pos = 0;
-        auto step = [&](int k, Entry &cur) {           // entry k: the stretch before its chunk, then the chunk
+        for (int k = 0; k <= n; ++k) {                 // entry k: the stretch before its chunk, then the chunk
+            if ((k & (kBriefBatch - 1)) == 0) {
+                store_batch();
+                fetch_batch(k + kBriefBatch);
+            }
+            const xv2 *b = reinterpret_cast<const xv2 *>(lbrief + (k & (kBriefBatch - 1)) * kBrief);
             const long end = (k < n) ? (long)uniform(lst[k]) : nchunks;
             if (pos < end) {
-#ifdef CG_WALK_CLOCKS
-                const long t_s = clock64();
-#endif
                 Summary st;
-                st.D = cur.st[0].x; st.mn = cur.st[0].y; st.mx = cur.st[1].x;
-                st.e = __double2loint(cur.st[1].y); st.bad = __double2hiint(cur.st[1].y);
-                const int es = exponent_of(s);
+                const xv2 s0 = b[16], s1 = b[17];
+                st.D = s0.x; st.mn = s0.y; st.mx = s1.x;
+                st.e = uniform(__double2loint(s1.y)); st.bad = uniform(__double2hiint(s1.y));
+                const int es = uniform(exponent_of(s));
                 const double S = (es == kNoExp) ? 0.0 : ldexp(s, 52 - es);
-                if (holds(st, es, S, (s == 0.0) && signbit(s))) {
+                if (uniform((int)holds(st, es, S, (s == 0.0) && signbit(s)))) {
                     if (st.e != kAnyExp) s = ldexp(S + st.D, es - 52);      // exact: integers below 2^53
                 } else {
                     ++n_groups;
                     s = walk_range(src, count, chunks, nchunks, groups, pos, end, s, lane, T, n_groups, n_chunks, tally);
                 }
-#ifdef CG_WALK_CLOCKS
-                clk_st += clock64() - t_s;
-#endif
             }
-            if (k < n) {
-                const long lo = end * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
+            if (k == n) break;
+            const long lo = end * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
+            const int e_g = uniform(lexp[k]);
+            ++n_chunks; ++n_planned;
+            // The prepared way: a run of pieces under e_g, one piece literally, a run under the binade reached.
+            bool done = false;
+            {
+                const xv2 b0 = b[0], b1 = b[1];
+                const int meta = uniform(__double2loint(b1.y)), fl = meta >> 8;
+                const int es = uniform(exponent_of(s));
+                if (!(fl & kBriefNoFast) && es != kNoExp && es == e_g) {
+                    double S = ldexp(s, 52 - es);
+                    bool ok = true;
+                    if (!(fl & kBriefNoBefore)) {
+                        const double a = S + b0.y, c = S + b1.x;
+                        ok = (S > 0.0) ? (a >= 0x1p52 + 1.0) && (c <= 0x1p53 - 1.0) : (c <= -(0x1p52 + 1.0)) && (a >= -(0x1p53 - 1.0));
+                        S += b0.x;                                            // exact if ok: integers below 2^53
+                    }
+                    if (uniform((int)ok)) {
+                        double t = ldexp(S, es - 52);
+                        if (!(fl & kBriefNoPiece)) {
+#pragma unroll
+                            for (int i = 0; i < kPerLane / 2; ++i) { const xv2 pp = b[2 + i]; t += pp.x; t += pp.y; }
+                        }
+                        if (fl & kBriefNoAfter) {
+                            s = t; done = true;
+                        } else {
+                            const int es2 = uniform(exponent_of(t)), h2 = es2 - e_g + 1;
+                            if (es2 != kNoExp && h2 >= 0 && h2 <= 2 && !((fl >> (1 + h2)) & 1)) {
+                                const double *ar = lbrief + (k & (kBriefBatch - 1)) * kBrief + 20 + 3 * h2;
+                                const double D = ar[0], mn = ar[1], mx = ar[2];
+                                const double S2 = ldexp(t, 52 - es2), a = S2 + mn, c = S2 + mx;
+                                const bool ok2 = (S2 > 0.0) ? (a >= 0x1p52 + 1.0) && (c <= 0x1p53 - 1.0)
+                                                            : (c <= -(0x1p52 + 1.0)) && (a >= -(0x1p53 - 1.0));
+                                if (uniform((int)ok2)) { s = ldexp(S2 + D, es2 - 52); done = true; }
+                            }
+                        }
+                    }
+                }
+            }
+            if (!done) {                               // the general way, from the chunk's start: its staged products and pieces
+                ++n_general;
+                const double *base = dump + (long)k * kEntry;
+                const xv2 *from = reinterpret_cast<const xv2 *>(base + lane * kPerLane);
+                const xv2 *fq = reinterpret_cast<const xv2 *>(base + kChunk + lane * kPieceDoubles);
                 double p[kPerLane];
                 Pieces pre;
 #pragma unroll
-                for (int i = 0; i < kPerLane / 2; ++i) { p[2 * i] = cur.p[i].x; p[2 * i + 1] = cur.p[i].y; }
-                const xv2 *q = cur.q;
-                pre.P0 = q[0].x; pre.lo0 = q[0].y; pre.hi0 = q[1].x;
-                pre.P1 = q[1].y; pre.lo1 = q[2].x; pre.hi1 = q[2].y;
-                pre.P2 = q[3].x; pre.lo2 = q[3].y; pre.hi2 = q[4].x;
-                pre.flags = __double2loint(q[4].y);
-                ++n_chunks; ++n_planned;
-#ifdef CG_WALK_CLOCKS
-                const long t_r = clock64();
-#endif
-                s = refine(p, pre, uniform(lexp[k]), lo, hi, s, lane, tally);
-#ifdef CG_WALK_CLOCKS
-                clk_ref += clock64() - t_r;
-#endif
-                pos = end + 1;
+                for (int i = 0; i < kPerLane / 2; ++i) { const xv2 v = from[i]; p[2 * i] = v.x; p[2 * i + 1] = v.y; }
+                const xv2 q0 = fq[0], q1 = fq[1], q2 = fq[2], q3 = fq[3], q4 = fq[4];
+                pre.P0 = q0.x; pre.lo0 = q0.y; pre.hi0 = q1.x;
+                pre.P1 = q1.y; pre.lo1 = q2.x; pre.hi1 = q2.y;
+                pre.P2 = q3.x; pre.lo2 = q3.y; pre.hi2 = q4.x;
+                pre.flags = __double2loint(q4.y);
+                s = refine(p, pre, e_g, lo, hi, s, lane, tally);
             }
-        };
-        fetch_entry(0, ent[0]);
-        fetch_entry(1, ent[1]);
-        for (int k = 0; k <= n; k += 2) {
-            step(k, ent[0]);
-            fetch_entry(k + 2, ent[0]);
-            if (k + 1 <= n) {
-                step(k + 1, ent[1]);
-                fetch_entry(k + 3, ent[1]);
-            }
+            pos = end + 1;
         }
     }
     if (lane == 0) {
         *result = s;
         if (stats != nullptr) {
             stats[0] = n_groups; stats[1] = n_chunks; stats[2] = tally[0]; stats[3] = tally[1]; stats[4] = n_planned;
+            stats[5] = n_general;
 #ifdef CG_WALK_CLOCKS
-            stats[5] = clock64() - clk_all; stats[6] = clk_st; stats[7] = clk_ref;
+            stats[6] = clock64() - clk_all;
 #endif
         }
     }
@@ -1226,7 +1331,7 @@ struct Workspace {
     long *stats = nullptr;                // what the last walks did: [8*which + 0..4], see k_xs_walk
     unsigned long long *marks = nullptr;  // per group: the chunks the walk is expected to take apart
     int *plist = nullptr, *pexp = nullptr, *pn = nullptr;  // the plan: those chunks in order, their predicted binades, how many
-    double *dump = nullptr;               // their products and prepared pieces (kEntry doubles each)
+    double *dump = nullptr;               // their products and prepared pieces (kEntry doubles each), then their briefs (kBrief each)
     unsigned long long *audit = nullptr;  // [0] failures counted by the self-check, [1] scratch (its second result)
     long cap_chunks = 0;
     // speculative path (reserve_spec): span sums under two hypotheses, the hypotheses of the two dot products of
@@ -1259,7 +1364,7 @@ struct Workspace {
         if ((e = hipMemset(pn, 0, 256)) != hipSuccess) return e;
         if ((e = hipMalloc(&audit, 256)) != hipSuccess) return e;
         if ((e = hipMemset(audit, 0, 256)) != hipSuccess) return e;
-        if ((e = hipMalloc(&dump, (size_t)(kPlanCap + 1) * kEntry * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&dump, (size_t)(kPlanCap + 1) * (kEntry + kBrief) * sizeof(double))) != hipSuccess) return e;
         cap_chunks = nc;
         return hipSuccess;
     }

@@ -1492,10 +1492,9 @@ int cg_get_option(cg_ctx *c, int key, long *value)
         }
         *value = st[1] * 1000000L + st[9];              // chunks taken apart: d.q walk * 10^6 + g.g walk
         if (const char *dbg = getenv("CG_DEBUG_WALK"))   // diagnostic: the whole tally on stderr
-            if (*dbg) fprintf(stderr, "walk d.q: groups %ld chunks %ld (planned %ld) rounds %ld blind %ld | g.g: groups %ld chunks %ld (planned %ld) rounds %ld blind %ld\n",
-                              st[0], st[1], st[4], st[2], st[3], st[8], st[9], st[12], st[10], st[11]);
-        if (getenv("CG_DEBUG_WALK") && (st[5] | st[13]))
-            fprintf(stderr, "walk clocks d.q: all %ld in stretches %ld in refine %ld | g.g: all %ld in stretches %ld in refine %ld\n", st[5], st[6], st[7], st[13], st[14], st[15]);
+            if (*dbg) fprintf(stderr, "walk d.q: groups %ld chunks %ld (planned %ld, brief failed %ld) rounds %ld blind %ld clocks %ld | "
+                              "g.g: groups %ld chunks %ld (planned %ld, brief failed %ld) rounds %ld blind %ld clocks %ld\n",
+                              st[0], st[1], st[4], st[5], st[2], st[3], st[6], st[8], st[9], st[12], st[13], st[10], st[11], st[14]);
         break;
     }
     case CG_OPT_COMM_REHEARSAL: *value = c->rehearse; break;
