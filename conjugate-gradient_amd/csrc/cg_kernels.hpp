@@ -546,6 +546,50 @@ __device__ __forceinline__ void span4_push(Span8 &st, int P, const SpanEntry &e,
     }
 }
 
+// Batches of four rows through LDS (kernels that keep fewer than eight rows in flight): every lane parks its
+// entries of the four rows in its wavefront's own LDS block -- quantity-and-row major, one double per lane, so the
+// stores are conflict-free and nothing is held in registers between rows -- and after the fourth row lane
+// 16*part + j adds up sixteen lanes' worth of quantity-and-row j; two swaps between halves and quarters of the
+// wavefront finish the sums, and lanes 0..15 store them: four consecutive rows of each span array.  About 60
+// instructions per batch against 130 for the exchange in registers; the sums are of integers (or approximate by
+// design), so their order is free.
+constexpr int kSpanStride = 65;                        // doubles per quantity-and-row in the LDS block (64 lanes + 1: the reads of the four parts fall on different banks)
+constexpr int kSpanLds = 16 * kSpanStride;             // doubles per wavefront
+template <bool NONNEG>
+__device__ __forceinline__ void span4_push_lds(double *R, int P, const SpanEntry &e, bool t0, bool t1, long m0, long m_lo,
+                                               long m_hi, long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
+{
+    const int lane = threadIdx.x & 63;
+    R[(0 + P) * kSpanStride + lane] = e.sub;
+    R[(4 + P) * kSpanStride + lane] = t0 ? __builtin_nan("") : e.D0;
+    R[(8 + P) * kSpanStride + lane] = t1 ? __builtin_nan("") : e.D1;
+    if (!NONNEG) R[(12 + P) * kSpanStride + lane] = (double)e.qf;
+    if (P == 3) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int j = lane & 15, part = lane >> 4;
+        const double *src = R + j * kSpanStride + part * 16;
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = src[i];
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) v[i] += v[i + w];
+        double y = v[0];
+        swap_add16(y, y);                               // every row of 16 lanes: its own part plus its neighbour's
+        swap_add32(y, y);                               // ... plus the other half's pair
+        const int q = j >> 2;
+        const long m = m0 + (j & 3);
+        double *arr = (q == 0) ? sub : (q == 1) ? spD0 : (q == 2) ? spD1 : spQ0;
+        if (q == 3) y = y * (1.0 + 0x1p-12) + 1.0;
+        if (lane < (NONNEG ? 12 : 16) && m >= m_lo && m < m_hi) arr[span_col + m] = y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the block's next use
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 constexpr int kHypNone = -30000;      // "no hypothesis": every non-zero product overflows under it, the span is redone later
 
 // The lower of the two exponent hypotheses for a span: `guess` is last iteration's prefix sum at the span, rho the
@@ -575,6 +619,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     if (a.sc != nullptr && a.sc->done) return;
 
     __shared__ double row_lds[2][W + 2];
+    __shared__ double span_lds[(NH > 0) ? kWaves * kSpanLds : 1];
     __shared__ double wave_slots[kWaves];
     const int tid = threadIdx.x;
     const long nwg = (long)gridDim.x;
@@ -797,7 +842,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
                         if (BATCH == 8) span8_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                        else span4_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        else span4_push_lds<true>(span_lds + (tid >> 6) * kSpanLds, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                     }
                 }
                 if (MODE == 5) {
@@ -826,7 +871,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
                         if (BATCH == 8) span8_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                        else span4_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        else span4_push_lds<false>(span_lds + (tid >> 6) * kSpanLds, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
                     }
                 }
                 if (WRITE_Q) {
