@@ -18,19 +18,25 @@ def find(sub, pat):
     hits = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
     return hits[0] if hits else None
 
+# Launches before the problem is first set up (k_init_d) belong to context creation: the placement draws time the
+# lean passes on candidate sets of vectors, most of which are then released.  They are left out of the table.
+def after_setup(rows, order_key):
+    rows = sorted(rows, key=lambda r: int(r[order_key]))
+    first = next((i for i, r in enumerate(rows) if "k_init_d" in r["Kernel_Name"]), 0)
+    return rows[first:]
+
 dur = defaultdict(list)
 kt = find("trace", "*kernel_trace.csv")
 if kt:
-    for row in csv.DictReader(open(kt)):
+    for row in after_setup(list(csv.DictReader(open(kt))), "Start_Timestamp"):
         dur[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 
 def counter(sub, name):
     acc = defaultdict(list)
     f = find(sub, "*counter_collection.csv")
     if f:
-        for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] == name:
-                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+        for row in after_setup([r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name], "Dispatch_Id"):
+            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     return acc
 
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
@@ -39,6 +45,8 @@ lines = [f"# rocprofv3 summary: {tag}", "",
          "Command: `python3 bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-parity` under `rocprofv3 --kernel-trace --stats`, "
          "then `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes.", "",
          "HBM bytes per launch = FETCH_SIZE x 1024 x 2 (gfx950 counts 128-B read requests as 64 B) + WRITE_SIZE x 1024.", "",
+         "Launches before the first `k_init_d` (context creation: the placement draws time the lean passes on candidate sets of "
+         "vectors) are left out of this table; rocprofv3's own `*_kernel_stats.csv` beside it counts them too.", "",
          "| kernel | calls | mean us | read MB/launch | write MB/launch | HBM GB/s (measured bytes) |", "|---|---|---|---|---|---|"]
 tot = sum(sum(v) for v in dur.values()) or 1
 for k in sorted(dur, key=lambda k: -sum(dur[k])):
