@@ -1341,6 +1341,11 @@ static int choose_placement(cg_ctx *c)
     if (draws < 2 || c->count < (1L << 27) || c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
     CGCHK(lean_setup(c));                               // the second gradient buffer belongs to the set
     if (c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
+    auto room = [&]() {                                 // a further set, and headroom for everything allocated later
+        size_t free_b = 0, total_b = 0;
+        return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 8 * c->padded_bytes;
+    };
+    if (!room()) return CG_OK;
     auto cost = [&](double *ms) -> int {                // two iterations of the lean schedule
         double t[3] = {0.0, 0.0, 0.0};
         for (int which = 0; which < 3; ++which) CGCHK(cg_time_kernel(c, which, 3, &t[which], nullptr));
@@ -1355,8 +1360,7 @@ static int choose_placement(cg_ctx *c)
     VectorSet rejected[8];
     int nrej = 0;
     for (int k = 1; rc == CG_OK && k < draws && k < 8; ++k) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 8 * c->padded_bytes) break;
+        if (!room()) break;
         VectorSet v;
         if (!alloc_vectors(v, c->padded_bytes)) break;
         adopt_vectors(c, v);
