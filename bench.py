@@ -259,7 +259,7 @@ def main():
                        "graph_iters": s.get_option(cg.lib.OPT_GRAPH_ITERS), "overlap": s.get_option(cg.lib.OPT_OVERLAP) if world > 1 else 0,
                        "transport": transport, "parallelism": f"rowblocks{world}",
                        # sets of vectors cg_create tries before it keeps the fastest placement (blocks of >= 2^27 points)
-                       "placement_draws": (int(os.environ.get("CG_PLACEMENT_DRAWS", "4")) if rows * G >= 1 << 27 else 1)},
+                       "placement_draws": (int(os.environ.get("CG_PLACEMENT_DRAWS", "8")) if rows * G >= 1 << 27 else 1)},
             "hbm_gbs_per_gpu": bpp * rows * G * its / 1e9,
             "hbm_frac_of_peak": bpp * rows * G * its / 1e9 / HBM_PEAK_GBS,
             "q1": res.q1, "iters_total": args.warmup + 2 * args.steps, "flush_ms": flush_ms,

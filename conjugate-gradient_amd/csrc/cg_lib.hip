@@ -1294,9 +1294,9 @@ int cg_stencil_noalloc(int device, long G, long row0, long rows, const double *d
 // that is stable for a given set (measured at 16384^2: 1.49 / 2.38 ms on a good set, 1.56-1.59 / 2.41-2.53 ms on
 // others; a fill of each single buffer takes the same time everywhere, it is how the streams of a pass meet in
 // the memory channels).  Offsets inside one large allocation were never better than separate allocations.  So a
-// context for a large grid draws up to four sets of vectors, times the three lean passes on each (zero data:
+// context for a large grid draws up to eight sets of vectors, times the three lean passes on each (zero data:
 // the kernels leave zeros behind) and keeps the fastest; the others are released afterwards, not in between,
-// or the driver would hand the same memory out again.  Costs ~0.15 s once (and 12 GiB per set at 16384^2 while it
+// or the driver would hand the same memory out again.  Costs ~0.35 s once (and 12 GiB per set at 16384^2 while it
 // lasts); CG_PLACEMENT_DRAWS=1 in the environment turns it off.
 struct VectorSet {
     double *u = nullptr, *q = nullptr, *g[2] = {nullptr, nullptr}, *d[2] = {nullptr, nullptr};
@@ -1336,7 +1336,7 @@ static bool alloc_vectors(VectorSet &v, size_t bytes)
 
 static int choose_placement(cg_ctx *c)
 {
-    int draws = 4;
+    int draws = 8;                                      // a good set turns up in one draw out of four to nine, depending on the box
     if (const char *e = getenv("CG_PLACEMENT_DRAWS")) draws = atoi(e);
     if (draws < 2 || c->count < (1L << 27) || c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
     CGCHK(lean_setup(c));                               // the second gradient buffer belongs to the set

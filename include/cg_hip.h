@@ -189,8 +189,8 @@ typedef struct cg_ctx cg_ctx;
 
 /* A context owns the row block [row0, row0+rows) x (n+1) of u, g, d, q on
  * `device`.  Single GPU: row0 = 0, rows = n+1, rank 0 of 1.
- * Blocks of 2^27 points or more: the vectors are allocated up to four times over, the passes of the default schedule
- * timed on each set, the fastest placement kept and the rest released (about 0.15 s, once; where the driver puts a
+ * Blocks of 2^27 points or more: the vectors are allocated up to eight times over, the passes of the default schedule
+ * timed on each set, the fastest placement kept and the rest released (about 0.35 s, once; where the driver puts a
  * vector in HBM changes the passes' speed by 5 % and more).  CG_PLACEMENT_DRAWS=1 in the environment turns that off. */
 int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks);
 int cg_destroy(cg_ctx *ctx);
