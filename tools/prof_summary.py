@@ -46,7 +46,9 @@ lines = [f"# rocprofv3 summary: {tag}", "",
          "then `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes.", "",
          "HBM bytes per launch = FETCH_SIZE x 1024 x 2 (gfx950 counts 128-B read requests as 64 B) + WRITE_SIZE x 1024.", "",
          "Launches before the first `k_init_d` (context creation: the placement draws time the lean passes on candidate sets of "
-         "vectors) are left out of this table; rocprofv3's own `*_kernel_stats.csv` beside it counts them too.", "",
+         "vectors) are left out of this table; rocprofv3's own `*_kernel_stats.csv` beside it counts them too. The passes' "
+         "times differ between processes by a few per cent with the placement the process ended up with (best of eight draws): "
+         "the HIP-event figures of a `bench.py` run and this table come from different processes.", "",
          "| kernel | calls | mean us | read MB/launch | write MB/launch | HBM GB/s (measured bytes) |", "|---|---|---|---|---|---|"]
 tot = sum(sum(v) for v in dur.values()) or 1
 for k in sorted(dur, key=lambda k: -sum(dur[k])):
