@@ -262,8 +262,12 @@ struct SrcStencil {
     Coef9 coef;
     long G, rows, row0, count;                          // G a multiple of kChunk: a chunk lies inside one row
     double beta;
-    static constexpr int kRow = kChunk + 8;             // d' of one row segment with its two outer columns, padded
+    // d' of one row segment with its two outer columns.  Every lane reads 16 consecutive columns, so column x sits
+    // at x + 2 + floor(x / 16): the lanes' blocks start 17 doubles apart and fall on different LDS banks (a stride
+    // of 16 doubles would put 32 lanes on the same bank).
+    static constexpr int kRow = kChunk + kChunk / 16 + 8;
     static constexpr int kLds = 3 * kRow;
+    static __device__ __forceinline__ int at(int x) { return x + 2 + (x >> 4); }      // x = -1 .. kChunk
     __device__ __forceinline__ void prepare() { beta = sc->beta; }
     __device__ __forceinline__ double dp(long k) const { return beta * d[k] - g[k]; }
     __device__ __forceinline__ double product(long k) const
@@ -305,25 +309,27 @@ struct SrcStencil {
         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
             for (int k = 0; k < kChunk / 128; ++k) {
-                double *dst = T + rr * kRow + 1 + k * 128 + 2 * lane;
+                double *dst = T + rr * kRow + at(k * 128 + 2 * lane);        // an even column and its neighbour: one block of 16
                 dst[0] = beta * dv[rr][k].x - gv[rr][k].x;
                 dst[1] = beta * dv[rr][k].y - gv[rr][k].y;
             }
-        if (lane < 6) T[(lane % 3) * kRow + ((lane < 3) ? 0 : kChunk + 1)] = edge;
+        if (lane < 6) T[(lane % 3) * kRow + ((lane < 3) ? at(-1) : at(kChunk))] = edge;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const bool row_in = (gi >= 1) && (gi <= G - 2);
-        const double *U = T + 1, *M = T + kRow + 1, *D = T + 2 * kRow + 1;
+        static_assert(kPerLane == 16, "the LDS layout pads after every 16 columns");
+        const double *U = T + at(lane * kPerLane), *M = U + kRow, *D = M + kRow;       // this lane's block: columns c .. c + 15 at [0 .. 15]
 #pragma unroll
         for (int i = 0; i < kPerLane; ++i) {
             const int c = lane * kPerLane + i;
             const long j = j0 + c;
             const bool in = row_in && (j >= 1) && (j <= G - 2);
+            const int l = (i == 0) ? -2 : i - 1, r = (i == kPerLane - 1) ? kPerLane + 1 : i + 1;   // the neighbours across the padding
             double q;
-            if (coef.nine) q = nine_point(coef, U[c - 1], U[c], U[c + 1], M[c - 1], M[c], M[c + 1], D[c - 1], D[c], D[c + 1]);
-            else q = five_point(coef, U[c], M[c - 1], M[c], M[c + 1], D[c]);
-            p[i] = (lo + c < hi) ? M[c] * (in ? q : 0.0) : 0.0;
+            if (coef.nine) q = nine_point(coef, U[l], U[i], U[r], M[l], M[i], M[r], D[l], D[i], D[r]);
+            else q = five_point(coef, U[i], M[l], M[i], M[r], D[i]);
+            p[i] = (lo + c < hi) ? M[i] * (in ? q : 0.0) : 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the buffer's next use
         __builtin_amdgcn_wave_barrier();

@@ -1379,7 +1379,7 @@ static int choose_placement(cg_ctx *c)
     HIPCHK(hipDeviceSynchronize());
     c->needs_init = false; c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->q_valid = true;
     drop_graph(c);
-    return rc;
+    return CG_OK;                                       // a timing that could not run only ends the draws: the context is as good as without them
 }
 
 int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks)
