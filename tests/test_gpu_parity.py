@@ -592,3 +592,21 @@ def test_smallest_grids_bitwise_or_close(cg, oracle, n, mode):
         assert np.array_equal(np.isnan(h), np.isnan(hr))              # 0/0 after an exactly zero residual, as in the reference
         assert np.all((h[~live] < 1e-25) | np.isnan(h[~live]))
         assert np.allclose(s.vector(cg.VEC_U), ref["u"], rtol=1e-11, atol=1e-15, equal_nan=True)
+
+
+def test_placement_draws_leave_a_fresh_context_and_the_same_results(cg, monkeypatch):
+    # a context for a large grid tries several sets of vectors at creation and keeps the fastest: whichever set it
+    # keeps, it must be indistinguishable from a context that never timed anything
+    n, iters = 16383, 12
+    s = cg.CGSolver(n)
+    for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+        assert not s.vector_rows(which, 0, 3).any() and not s.vector_rows(which, n - 2, 3).any()
+    r = s.configure(reduce=cg.REDUCE_STRICT).init_problem().solve(iters)
+    monkeypatch.setenv("CG_PLACEMENT_DRAWS", "1")
+    s1 = cg.CGSolver(n)
+    r1 = s1.configure(reduce=cg.REDUCE_STRICT).init_problem().solve(iters)
+    assert float(r.q1).hex() == float(r1.q1).hex()
+    for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+        for row in (0, 1, 8191, n - 1):
+            assert np.array_equal(s.vector_rows(which, row, 2).view(np.uint64), s1.vector_rows(which, row, 2).view(np.uint64))
+    s.close(); s1.close()
