@@ -1341,9 +1341,12 @@ static int choose_placement(cg_ctx *c)
     if (draws < 2 || c->count < (1L << 27) || c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
     CGCHK(lean_setup(c));                               // the second gradient buffer belongs to the set
     if (c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
-    auto room = [&]() {                                 // a further set, and headroom for everything allocated later
-        size_t free_b = 0, total_b = 0;
-        return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 8 * c->padded_bytes;
+    size_t free_start = 0;
+    auto room = [&]() {                                 // a further set, headroom for everything allocated later, and never
+        size_t free_b = 0, total_b = 0;                 // more than half of what was free (other ranks may share the GPU)
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+        if (free_start == 0) free_start = free_b;
+        return free_b >= 8 * c->padded_bytes && free_b - 6 * c->padded_bytes >= free_start / 2;
     };
     if (!room()) return CG_OK;
     auto cost = [&](double *ms) -> int {                // two iterations of the lean schedule
