@@ -110,6 +110,22 @@ def test_subnormal_accumulator(cg, oracle, rng):
     check(cg, oracle, v, np.ones(n))
 
 
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_one_crossing_in_a_chosen_piece_of_a_chunk(cg, oracle, rng, sign):
+    # the walk's prepared path per marked chunk: a run of sixteen-element pieces, ONE piece added literally, a run
+    # behind it -- with the crossing in the first piece (no run before), the last (no run behind), in between, at
+    # the chunk's very start and end; accumulator rising through a power of two and falling through it; ragged tail
+    n = 5 * 1024 + 77
+    v = rng.uniform(0.5, 1.5, n)
+    for m in (0, 1, 15, 16, 17, 500, 1007, 1008, 1023, 1024, 1025, 2048 + 16 * 63 - 1, 4 * 1024 + 33, n - 3):
+        up = float(np.sum(v[:m]))
+        check(cg, oracle, sign * v, np.ones(n), start=sign * (2.0 ** 20 - up))          # |s| grows through 2^20 near element m
+        check(cg, oracle, -sign * v, np.ones(n), start=sign * (2.0 ** 20 + up))         # |s| falls through 2^20 near element m
+    w = v.copy()
+    w[1500:1600] *= -1.0                                                                # back and forth across the boundary inside one chunk
+    check(cg, oracle, sign * w, np.ones(n), start=sign * (2.0 ** 20 - float(np.sum(v[:1490]))))
+
+
 def test_smooth_fields_like_the_solver(cg, oracle):
     # the actual operands: d0 and q = A d0 on a 1024^2 grid, and g.g
     n = 1023
