@@ -1109,6 +1109,12 @@ int cg_dot(int device, long count, const double *v, const double *w, int strict,
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(result_host, sc->slot, sizeof(double), hipMemcpyDeviceToHost, sc->stream));
         HIPCHK(hipStreamSynchronize(sc->stream));
+        if (getenv("CG_DEBUG_WALK") && sc->xs.stats && use_parallel_strict(strict, count)) {      // diagnostic: the walk's tally
+            long st[8];
+            HIPCHK(hipMemcpy(st, sc->xs.stats, sizeof st, hipMemcpyDeviceToHost));
+            fprintf(stderr, "cg_dot walk: stretches walked %ld chunks %ld (planned %ld, brief failed %ld) rounds %ld blind %ld\n",
+                    st[0], st[1], st[4], st[5], st[2], st[3]);
+        }
         return CG_OK;
     }
     const int vec = (count % 2 == 0 && aligned16(v) && aligned16(w)) ? 2 : 1;
