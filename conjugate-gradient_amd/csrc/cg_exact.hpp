@@ -33,8 +33,13 @@
 //      the accumulator changes its binade), so the marked chunks are listed in order, their
 //      products and the summaries of their 16-element pieces (under the three binades around the
 //      predicted one, in prefix form) are staged, and each stretch between two marked chunks is
-//      composed into ONE summary: the walk applies a stretch in one step, takes the marked chunk
-//      apart with what was staged, and has the next two entries in flight (k_xs_plan, k_xs_walk).
+//      composed into ONE summary.  For each marked chunk the plan goes one step further (the
+//      brief, kBrief): the approximation is good enough to tell which ONE piece the crossing falls
+//      into, so the pieces before it and behind it are composed into two summaries and that
+//      piece's sixteen products are copied next to them.  The walk applies a stretch in one step,
+//      then the chunk by its brief -- a range test, sixteen additions, a range test, all on
+//      wave-uniform values read from LDS -- and takes the chunk apart with the staged products and
+//      piece summaries only where a test fails (k_xs_plan, k_xs_walk).
 //      A plan that turns out wrong costs time, never a bit: every summary is judged by the true
 //      accumulator, and the walk falls back to the hierarchical descent of D.
 // Failures are rare: each binade crossing of the accumulator (a few dozen per dot

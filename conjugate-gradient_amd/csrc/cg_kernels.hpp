@@ -362,8 +362,8 @@ struct RawRow {
 // magnitudes is at most their total, and |partial D| <= partial Q); a half-way case anywhere in the span turns
 // that hypothesis' D into a NaN.
 // The sums over the 64 lanes are NOT formed row by row (four dependent data-parallel reductions per row cost
-// more than the rest of the pass): the entries of four or eight consecutive rows are reduced together in
-// registers, the lanes trading rows (span4_push / span8_push below).
+// more than the rest of the pass): the entries of four consecutive rows are reduced together through LDS
+// (span4_push_lds), those of eight in registers, the lanes trading rows (span8_push).
 struct SpanEntry {
     double sub, D0, D1;
     float qf;
@@ -504,48 +504,6 @@ __device__ __forceinline__ void span8_push(Span8 &st, int P, const SpanEntry &e,
     }
 }
 
-// The same for batches of four rows (a kernel that keeps four rows of loads in flight): halves, then quarters, and
-// a sum over sixteen lanes; the sixteen lanes 16k .. 16k+15 end up with row [0, 2, 1, 3][k], lane 16k stores.
-__device__ __forceinline__ double four_finish(double y)
-{
-    y += dpp_move<0xB1>(y);                                          // quad_perm [1,0,3,2]
-    y += dpp_move<0x4E>(y);                                          // quad_perm [2,3,0,1]
-    y += dpp_move<0x141>(y);                                         // row_half_mirror
-    y += dpp_move<0x140>(y);                                         // row_mirror
-    return y;
-}
-template <bool NONNEG>
-__device__ __forceinline__ void span4_push(Span8 &st, int P, const SpanEntry &e, bool t0, bool t1, long m0, long m_lo, long m_hi,
-                                           long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
-{
-    SpanQuad cur;
-    cur.su = e.sub;
-    cur.d0 = t0 ? __builtin_nan("") : e.D0;
-    cur.d1 = t1 ? __builtin_nan("") : e.D1;
-    cur.q = NONNEG ? 0.0 : (double)e.qf;
-    if ((P & 1) == 0) {
-        st.pend = cur;
-    } else {
-        const SpanQuad w = quad_swap32<NONNEG>(st.pend, cur);
-        if ((P & 2) == 0) {
-            st.wpend = w;
-        } else {
-            const SpanQuad x = quad_swap16<NONNEG>(st.wpend, w);
-            const double rs = four_finish(x.su), r0 = four_finish(x.d0), r1 = four_finish(x.d1);
-            double rq = 0.0;
-            if (!NONNEG) rq = four_finish(x.q);
-            const int lane = threadIdx.x & 63, k = lane >> 4;
-            const long m = m0 + (((k & 1) << 1) | (k >> 1));
-            if ((lane & 15) == 0 && m >= m_lo && m < m_hi) {
-                sub[span_col + m] = rs;
-                spD0[span_col + m] = r0;
-                spD1[span_col + m] = r1;
-                if (!NONNEG) spQ0[span_col + m] = rq * (1.0 + 0x1p-12) + 1.0;
-            }
-        }
-    }
-}
-
 // Batches of four rows through LDS (kernels that keep fewer than eight rows in flight): every lane parks its
 // entries of the four rows in its wavefront's own LDS block -- quantity-and-row major, one double per lane, so the
 // stores are conflict-free and nothing is held in registers between rows -- and after the fourth row lane
@@ -610,7 +568,7 @@ __device__ __forceinline__ int hyp_exponent(double guess, double rho)
 template <int VEC, int MODE, bool WRITE_Q, int PF, bool CONTIG, int NH = 0>
 // Resident workgroups per CU the register budget is cut for: one for the writing passes, two for the read-only pass,
 // three for the read-only pass that also forms the strict-order span sums (bound by its instruction stream, not by
-// memory: every further wavefront per SIMD helps) when it keeps at most two rows in flight (157 registers).
+// memory: every further wavefront per SIMD helps) when it keeps at most two rows in flight (147 registers).
 __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2) : 1) void k_stencil(const StencilArgs a)
 {
     constexpr bool FUSE_D = (MODE == 1 || MODE >= 3);                // operands are d and g, d' is formed here
@@ -736,7 +694,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     int buf = 0;
     // Rows r0-1 .. r1 in groups of PF; a group may run past r1, those rows are fully
     // masked (zero loads, dropped stores, zero contributions to the partial sum).
-    // NH > 0: the span sums of a batch of four or eight rows are reduced over the wavefront together (span4_push,
+    // NH > 0: the span sums of a batch of four or eight rows are reduced over the wavefront together (span4_push_lds,
     // span8_push); a kernel that keeps fewer than four rows in flight goes through its ring twice or four times per batch.
     constexpr int BATCH = (NH > 0 && PF < 4) ? 4 : PF;
     static_assert(NH == 0 || BATCH == 4 || BATCH == 8, "the span sums are reduced in batches of four or eight rows");

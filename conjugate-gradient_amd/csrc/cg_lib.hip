@@ -346,8 +346,8 @@ TileGeom ctx_geom(const cg_ctx *c)
     for (int m = 0; m < 6; ++m) t.pf_mode[m] = c->prefetch > 0 ? c->prefetch : auto_pf[m];
     if (c->prefetch_read > 0) t.pf_mode[3] = c->prefetch_read;
     // With the span sums of the strict order the read-only pass is bound by its instruction stream and its
-    // registers, not by memory latency: two rows in flight leave it 157 registers, enough for three workgroups
-    // per CU (dq_geom), and the four-row batched reduction does the rest.
+    // registers, not by memory latency: two rows in flight leave it 147 registers, enough for three workgroups
+    // per CU (dq_geom), and the four-row batched reduction through LDS does the rest.
     t.pf_spec_read = c->prefetch_read > 0 ? c->prefetch_read : (c->prefetch > 0 ? c->prefetch : 2);
     t.pf = t.pf_mode[0];
     if (c->tile_wgs > 0) t.max_wgs = c->tile_wgs;
