@@ -138,6 +138,7 @@ struct TileGeom {
     int pf = 4;       // rows of loads in flight per thread (stand-alone entry point)
     int pf_mode[6] = {4, 4, 4, 4, 4, 4};   // ... per kernel mode (solver context)
     int pf_spec_read = 4;                  // ... of the read-only pass when it also forms the strict-order span sums
+    int pf_spec_u = 1;                     // ... of pass 2 with the u update when it does (one row: measured, 1-2 % over two)
     int wg_mult = 2;                       // workgroups per CU of the read-only pass
     bool plain_order = false;              // the read-only pass takes its tiles in plain order (no XCD-aware placement)
     int vec;          // 2 when rows are 16-byte aligned (even G), else 1
@@ -208,7 +209,7 @@ long launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
     const dim3 grid((unsigned)nwg), block(kBlock);
 #define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C, NH>), grid, block, 0, s, a)
     if (NH > 0) {                     // speculative strict summaries: 16-byte rows in the context's layout only
-        switch (MODE == 3 ? t.pf_spec_read : t.pf_mode[MODE]) {
+        switch (MODE == 3 ? t.pf_spec_read : (MODE == 5 ? t.pf_spec_u : t.pf_mode[MODE])) {
         case 1: CG_LAUNCH(2, 1, true); break;
         case 4: CG_LAUNCH(2, 4, true); break;
         case 8: CG_LAUNCH(2, 8, true); break;
@@ -258,6 +259,7 @@ struct cg_ctx {
     long flat_blocks_opt = 0;
     int prefetch = 0;                     // 0 = per-kernel defaults (see ctx_geom)
     int prefetch_read = 0;                // read-only pass of the lean schedule; 0 = default
+    int pf_update_u = 0;                  // pass 2 with the u update: what choose_placement measured (0 = default)
     long tile_wgs = 0;
     bool graph_explicit = false;          // the caller set CG_OPT_GRAPH_ITERS
     int overlap = 1;                      // multi-rank lean schedule: halo exchange beside the interior rows
@@ -338,17 +340,21 @@ namespace {
 TileGeom ctx_geom(const cg_ctx *c)
 {
     TileGeom t = tile_geom(c->G, c->rows, true, c->tile_h);
-    // Rows of loads in flight per thread.  Measured at 16384^2 with 256 workgroups: the pure read
-    // pass wants as much in flight as it can get (8 rows: 6.7 TB/s against 5.6 at 4), the mixed
-    // read/write passes are fastest with LITTLE in flight, the more streams the less: two rows for
-    // 2R2W (5.85 TB/s against 5.6 at 4 and 4.6 at 1), one for 3R3W (5.4 against 5.1 at 4).
-    static const int auto_pf[6] = {4, 4, 4, 8, 2, 1};
+    // Rows of loads in flight per thread.  Measured at 16384^2: the mixed read/write passes are fastest with
+    // LITTLE in flight: two rows for 2R2W (5.85 TB/s against 5.6 at 4 and 4.6 at 1); for 3R3W two rows on most
+    // grids, blocks and placements (2-5 % over one row), one row on some placements of the 16384^2 grid (1.5 %
+    // the other way), so a context that times its placement times both (choose_placement).  The pure read pass
+    // with two workgroups per CU: four rows (1.5-4 % over eight from 2048-row blocks to 65536^2; with one
+    // workgroup per CU it wanted eight).
+    static const int auto_pf[6] = {4, 4, 4, 4, 2, 2};
     for (int m = 0; m < 6; ++m) t.pf_mode[m] = c->prefetch > 0 ? c->prefetch : auto_pf[m];
+    if (c->prefetch == 0 && c->pf_update_u > 0) t.pf_mode[5] = c->pf_update_u;
     if (c->prefetch_read > 0) t.pf_mode[3] = c->prefetch_read;
     // With the span sums of the strict order the read-only pass is bound by its instruction stream and its
     // registers, not by memory latency: two rows in flight leave it 147 registers, enough for three workgroups
     // per CU (dq_geom), and the four-row batched reduction through LDS does the rest.
     t.pf_spec_read = c->prefetch_read > 0 ? c->prefetch_read : (c->prefetch > 0 ? c->prefetch : 2);
+    t.pf_spec_u = c->prefetch > 0 ? c->prefetch : 1;
     t.pf = t.pf_mode[0];
     if (c->tile_wgs > 0) t.max_wgs = c->tile_wgs;
     t.contig = 1;
@@ -623,7 +629,7 @@ int enqueue_lean_iteration(cg_ctx *c)
         ti = tile_geom(c->G, c->rows - 2 * kEdgeRows, true, c->tile_h);
         ti.contig = 1; ti.pf = t.pf; ti.max_wgs = t.max_wgs;
         for (int m = 0; m < 6; ++m) ti.pf_mode[m] = t.pf_mode[m];
-        ti.pf_spec_read = t.pf_spec_read;
+        ti.pf_spec_read = t.pf_spec_read; ti.pf_spec_u = t.pf_spec_u;
         n_gg = 2 * (long)t.nstrips + ti.ntiles;
     }
     double *p_dq, *p_gg;
@@ -1344,7 +1350,7 @@ static int choose_placement(cg_ctx *c)
 {
     int draws = 8;                                      // a good set turns up in one draw out of four to nine, depending on the box
     if (const char *e = getenv("CG_PLACEMENT_DRAWS")) draws = atoi(e);
-    if (draws < 2 || c->count < (1L << 27) || c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
+    if (draws < 1 || c->count < (1L << 27) || c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
     CGCHK(lean_setup(c));                               // the second gradient buffer belongs to the set
     if (c->effective_schedule() != CG_SCHED_LEAN) return CG_OK;
     size_t free_start = 0;
@@ -1355,17 +1361,22 @@ static int choose_placement(cg_ctx *c)
         return free_b >= 8 * c->padded_bytes && free_b - 6 * c->padded_bytes >= free_start / 2;
     };
     if (!room()) return CG_OK;
-    auto cost = [&](double *ms) -> int {                // two iterations of the lean schedule
-        double t[3] = {0.0, 0.0, 0.0};
-        for (int which = 0; which < 3; ++which) CGCHK(cg_time_kernel(c, which, 3, &t[which], nullptr));
-        *ms = 2.0 * t[0] + t[1] + t[2];
+    auto cost = [&](double *ms, int *pf_u) -> int {     // two iterations of the lean schedule; the six-stream pass with
+        double t[4] = {0.0, 0.0, 0.0, 0.0};             // one and with two rows in flight (which is better depends on the set)
+        for (int which = 0; which < 4; ++which) {
+            c->pf_update_u = (which == 3) ? 1 : 2;
+            CGCHK(cg_time_kernel(c, which < 3 ? which : 2, 3, &t[which], nullptr));
+        }
+        *pf_u = (t[3] < t[2]) ? 1 : 2;
+        *ms = 2.0 * t[0] + t[1] + 0.5 * (t[2] + t[3]);   // both forms count: the strict order keeps one row in flight there
         return CG_OK;
     };
     VectorSet best;
     best.u = c->u_alloc; best.q = c->q_alloc; best.g[0] = c->g_alloc[0]; best.g[1] = c->g_alloc[1];
     best.d[0] = c->d_alloc[0]; best.d[1] = c->d_alloc[1];
     double best_ms = 0.0;
-    int rc = cost(&best_ms);
+    int best_pf = 0;
+    int rc = cost(&best_ms, &best_pf);
     VectorSet rejected[8];
     int nrej = 0;
     for (int k = 1; rc == CG_OK && k < draws && k < 8; ++k) {
@@ -1374,12 +1385,14 @@ static int choose_placement(cg_ctx *c)
         if (!alloc_vectors(v, c->padded_bytes)) break;
         adopt_vectors(c, v);
         double ms = 0.0;
-        rc = cost(&ms);
+        int pf = 0;
+        rc = cost(&ms, &pf);
         if (getenv("CG_DEBUG_PLACEMENT")) fprintf(stderr, "placement draw %d: %.3f ms per two iterations (best so far %.3f)\n", k, ms, best_ms);
-        if (rc == CG_OK && ms < 0.995 * best_ms) { rejected[nrej++] = best; best = v; best_ms = ms; }
+        if (rc == CG_OK && ms < 0.995 * best_ms) { rejected[nrej++] = best; best = v; best_ms = ms; best_pf = pf; }
         else rejected[nrej++] = v;
     }
     adopt_vectors(c, best);
+    c->pf_update_u = (rc == CG_OK) ? best_pf : 0;
     for (int k = 0; k < nrej; ++k) rejected[k].release();
     // back to the state of a fresh context
     double *all[6] = {best.u, best.q, best.g[0], best.g[1], best.d[0], best.d[1]};

@@ -159,7 +159,7 @@ typedef struct cg_ctx cg_ctx;
                                   kernel; 0 = measured per-kernel defaults (default) */
 #define CG_OPT_STRICT_IMPL 8   /* how the strict order is evaluated: 1 = auto (default), 2 = literal
                                   one-accumulator replay, 3 = parallel evaluation (same bits, see cg_dot) */
-#define CG_OPT_PREFETCH_READ 11 /* same for LEAN's read-only pass alone; 0 = default (8; 2 when it also forms the span sums
+#define CG_OPT_PREFETCH_READ 11 /* same for LEAN's read-only pass alone; 0 = default (4; 2 when it also forms the span sums
                                   of CG_OPT_STRICT_SPEC, which then runs three workgroups per CU) */
 #define CG_OPT_STRICT_BLOCKS 12 /* with CG_REDUCE_STRICT on one GPU: s = 2, 4 or 8 sums every dot product in the
                                   layout of the reference run on s*s MPI ranks -- each rank's (G/s)^2 block
