@@ -10,7 +10,10 @@ the same grid over the ranks (strong scaling), halo rows and dot products going
 through RCCL inside the library.  Inputs are the reference's own closed-form
 right-hand side (no RNG), generated on the device before the timed region.
 
-Rank 0 prints ONE JSON line.  `value` is whole-job iterations/sec.  `roofline`
+Rank 0 prints ONE JSON line.  `value` is whole-job iterations/sec over the reference's timed region
+(cg.c:50-55,131-134: the dot product g.g, K iterations, every vector final) in the reference's own summation
+order, whose results are bit-identical to the reference's; `other_order` gives the same for the documented
+parallel order.  `roofline`
 describes the dominant kernel (HIP-event timed on the solver's own stream inside
 this run); `cpu_baseline` is the reference's CPU path timed on this box's host
 cores on a bounded sample (N = 1 only).
@@ -87,8 +90,8 @@ def parity_run(cg, s, n):
                 "q1_hex": float(r.q1).hex(), "reference_q1_hex": float.fromhex(rec["q1_hex"]).hex(),
                 "bit_identical": float(r.q1).hex() == float.fromhex(rec["q1_hex"]).hex(),
                 "it_per_s": r.iters / r.seconds,
-                "fast_order_note": "the timed run uses the documented parallel order; its q1 differs from the "
-                                   "reference's by 1e-9..2e-7 relative depending on size and iteration count"}
+                "note": "a fresh solve: initial g.g and the first iterations (which have no hypotheses for the "
+                        "sequential sums yet) included, the final d / u updates not"}
     except Exception as e:                      # side information must never take the benchmark down
         return {"error": str(e)}
 
@@ -134,9 +137,10 @@ def main():
     ap.add_argument("--n", "--grid-n", dest="n", type=int, default=16383,
                     help="argv n of the reference: grid side is n+1 (--grid-n: the spelling that survives torch.distributed.run)")
     ap.add_argument("--schedule", choices=["classic", "fused", "fused_noq", "lean"], default="lean")
-    ap.add_argument("--reduce", choices=["fast", "strict"], default="fast",
-                    help="reduction order of the timed run: the documented parallel order (default), or the reference's own "
-                         "(one accumulator, index order: bit-identical results)")
+    ap.add_argument("--reduce", choices=["fast", "strict"], default="strict",
+                    help="reduction order of the timed run: the reference's own (one accumulator, index order: results "
+                         "bit-identical to the reference; default), or the documented parallel order")
+    ap.add_argument("--no-side", action="store_true", help="skip the timed region in the other reduction order (side figure)")
     ap.add_argument("--tile-h", type=int, default=0)
     ap.add_argument("--graph-iters", type=int, default=None,
                     help="iterations per captured hipGraph (default: 10 on one GPU; eager launches with RCCL)")
@@ -219,29 +223,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    s.init_problem()
-    if args.warmup > 0:
-        s.solve(args.warmup)                 # untimed
-        s.solve(args.steps)                  # untimed rehearsal of the timed call: captures the hipGraph for the buffer
-                                             # roles that call starts in, sizes the history buffer
-    fence()
-    # The timed call continues the solve: K more iterations, each carrying one stencil application, both dot
-    # products and the three vector updates.  The lean schedule folds d = beta*d - g and every other u += tau*d
-    # into the following iteration's kernels, so the window holds the updates the warm-up's last iteration left
-    # owed and leaves its own last ones owed in turn -- exactly K of each operation either way.  What it takes to
-    # bring u and d up to date afterwards (needed once, when somebody reads them) is reported as flush_ms.
-    t0 = time.perf_counter()
-    res = s.solve(args.steps)                # exactly K iterations
-    fence()
-    elapsed = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    s.sync_vectors()
-    fence()
-    flush_ms = 1e3 * (time.perf_counter() - t1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(order):
+        """W warm-up iterations, then the reference's timed region (cg.c:50-55,131-134) around exactly K iterations on the
+        warm vectors: the dot product q0 = g.g, the K iterations, and the d / u updates the lean schedule's last iteration
+        still owes (cg_sync_vectors), device-synchronised at both ends, max over ranks.  Returns (seconds, result, steady):
+        `steady` is the library's own clock around a further K iterations that neither begin with g.g nor end with the
+        flush -- the per-iteration cost a long solve converges to."""
+        s.configure(reduce=cg.REDUCE_STRICT if order == "strict" else cg.REDUCE_FAST, schedule=sched)
+        s.init_problem()
+        s.set_option(cg.lib.OPT_RESUM_Q0, 1)
+        if args.warmup > 0:
+            s.solve(args.warmup)                 # untimed
+            s.sync_vectors()
+            s.solve(args.steps)                  # untimed rehearsal of the timed call: captures the hipGraph for the buffer
+            s.sync_vectors()                     # roles that call starts in, sizes the history buffer
+        fence()
+        t0 = time.perf_counter()
+        res = s.solve(args.steps)                # g.g, then exactly K iterations
+        s.sync_vectors()                         # ... and what the last of them left owed
+        fence()
+        elapsed = time.perf_counter() - t0
+        s.set_option(cg.lib.OPT_RESUM_Q0, 0)
+        s.solve(2)                               # leaves the state a steady-state iteration starts from
+        st = s.solve(args.steps)
+        steady = st.seconds / max(st.iters, 1)
+        if world > 1:
+            t = torch.tensor([elapsed, steady], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, steady = float(t[0].item()), float(t[1].item())
+        return elapsed, res, steady
+
+    side_order = "fast" if args.reduce == "strict" else "strict"
+    side = None if args.no_side else timed_region(side_order)
+    elapsed, res, steady = timed_region(args.reduce)      # the headline order runs last: its state is what the roofline timings follow
 
     out = None
     if rank == 0:
@@ -262,9 +276,16 @@ def main():
                        "placement_draws": (int(os.environ.get("CG_PLACEMENT_DRAWS", "8")) if rows * G >= 1 << 27 else 1)},
             "hbm_gbs_per_gpu": bpp * rows * G * its / 1e9,
             "hbm_frac_of_peak": bpp * rows * G * its / 1e9 / HBM_PEAK_GBS,
-            "q1": res.q1, "iters_total": args.warmup + 2 * args.steps, "flush_ms": flush_ms,
+            "q1": res.q1, "iters_total": args.warmup + 3 * args.steps + 2,
+            "timed_region": "q0 = g.g, K iterations, the owed d / u updates (cg.c:50-55,131-134), warm vectors",
+            "steady_state": {"ms_per_step": 1e3 * steady, "it_per_s": 1.0 / steady,
+                             "hbm_frac_of_peak": bpp * rows * G / steady / 1e9 / HBM_PEAK_GBS,
+                             "note": "K further iterations without the leading g.g and the trailing updates"},
             "source_id": source_id(),
         }
+        if side is not None:
+            out["other_order"] = {"reduce": side_order, "it_per_s": args.steps / side[0], "ms_per_step": 1e3 * side[0] / args.steps,
+                                  "steady_ms_per_step": 1e3 * side[2], "q1": side[1].q1}
     # per-kernel roofline: HIP events on the solver's stream, this run, this GPU (rank 0's row block)
     if rank == 0:
         names = {cg.SCHED_CLASSIC: ("stencil", "update", "dupdate"), cg.SCHED_FUSED: ("stencil", "update"),
@@ -287,21 +308,11 @@ def main():
             return roof, kern
 
         out["roofline"], out["kernels"] = kernel_roofline(args.reduce)
-        out["parity"] = None
-        if world == 1 and not args.no_parity and args.reduce == "fast":
-            # the same grid in the reference's summation order (bit-identical to the reference): its rate, and the
-            # roofline of its kernels -- the same passes, which there also summarise their products for the
-            # sequential sum (algorithmic bytes are the schedule's; the summaries add about 1 B per point)
-            out["parity"] = parity_run(cg, s, n)
-            if out["parity"] and "it_per_s" in out["parity"]:
-                s.configure(reduce=cg.REDUCE_STRICT, schedule=-1).init_problem()
-                s.solve(4)
-                roof, kern = kernel_roofline("strict")
-                its_s = out["parity"]["it_per_s"]
-                roof["it_per_s"] = its_s
-                roof["whole_iteration_gbs"] = bpp * rows * G * its_s / 1e9
-                roof["whole_iteration_frac"] = bpp * rows * G * its_s / 1e9 / HBM_PEAK_GBS
-                out["roofline_strict"], out["kernels_strict"] = roof, kern
+        out["roofline"]["whole_iteration_frac"] = out["steady_state"]["hbm_frac_of_peak"]
+        out["roofline"]["timed_region_frac"] = out["hbm_frac_of_peak"]
+        # the same grid from a fresh start in the reference's summation order for the iteration count the reference
+        # itself was run with: q1 must equal the reference's bit for bit (untimed proof; its rate is side information)
+        out["parity"] = parity_run(cg, s, n) if (world == 1 and not args.no_parity) else None
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(n)
     if world > 1:
         dist.barrier()                       # no rank tears its communicator down while another still solves

@@ -1066,6 +1066,9 @@ __global__ __launch_bounds__(64) void k_dot_strict(const double *__restrict__ v,
 //   what 5: a solve that continues the previous one: q0 is the q1 the last iteration left (the same
 //           g.g, cg.c:55 and :89 hold the same value), so nothing is summed; q_init, stop and the
 //           history origin are set for the new solve
+//   what 6: a solve that continues the previous one but sums g.g once more, as the reference's timed
+//           region does (cg.c:55): q0, q_init and stop from the sum; the iteration count, the deferred
+//           u updates and beta (the d update still owed needs it) stay
 // With `strict_src` the sum is taken from there instead of the partials: one value (the
 // strict-order result), or `nsrc` values added in index order.
 __device__ __forceinline__ double sum_partials(const double *partials, long count, double *wave_slots)
@@ -1127,6 +1130,13 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
         sc->iter = 0;
         sc->iter_base = 0;
         sc->u_applied = 0;
+        sc->done = 0;
+    } else if (what == 6) {
+        sc->q0 = s;
+        sc->q1 = s;
+        sc->q_init = s;
+        sc->stop = rtol * rtol * s;
+        sc->iter_base = sc->iter;
         sc->done = 0;
     } else if (what == 5) {
         sc->q_init = sc->q0;

@@ -264,6 +264,7 @@ struct cg_ctx {
     bool graph_explicit = false;          // the caller set CG_OPT_GRAPH_ITERS
     int overlap = 1;                      // multi-rank lean schedule: halo exchange beside the interior rows
     int rehearse = 0;                     // single rank with an RCCL communicator: issue the multi-rank traffic anyway
+    int resum_q0 = 0;                     // a solve that continues the previous one sums q0 = g.g again (cg.c:55) instead of taking it over
 
     // device state
     hipStream_t stream = nullptr;
@@ -1540,6 +1541,7 @@ int cg_set_option(cg_ctx *c, int key, long value)
         if (c->strict_blocks != value) c->live = false;
         c->strict_blocks = value; break;
     case CG_OPT_OVERLAP: c->overlap = value ? 1 : 0; break;
+    case CG_OPT_RESUM_Q0: c->resum_q0 = value ? 1 : 0; break;
     case CG_OPT_STRICT_SPEC: c->strict_spec = value ? 1 : 0; break;
     case CG_OPT_STRICT_AUDIT: c->strict_audit = value ? 1 : 0; drop_graph(c); break;
     case CG_OPT_COMM_REHEARSAL:
@@ -1579,6 +1581,7 @@ int cg_get_option(cg_ctx *c, int key, long *value)
     case CG_OPT_STRICT_BLOCKS: *value = c->strict_blocks; break;
     case CG_OPT_TILE_WGS: *value = ctx_geom(c).max_wgs; break;
     case CG_OPT_OVERLAP: *value = c->overlap; break;
+    case CG_OPT_RESUM_Q0: *value = c->resum_q0; break;
     case CG_OPT_STRICT_SPEC: *value = c->strict_spec; break;
     case CG_OPT_STRICT_AUDIT: {                         // failures the self-check has counted so far (0 when it is off)
         unsigned long long n = 0;
@@ -1746,12 +1749,12 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     HIPCHK(hipStreamSynchronize(s));
 
     const auto t0 = std::chrono::steady_clock::now();
-    if (cont) {
+    if (cont && !c->resum_q0) {
         hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, (const double *)nullptr, 0L, (const double *)nullptr, 1,
                            c->sc, 5, rtol, c->hist, c->hist_cap);
         HIPCHK(hipGetLastError());
     } else {
-        // q0 = g.g (cg.c:55)
+        // q0 = g.g (cg.c:55); a continuing solve keeps its iteration count and what it owes (k_finish, what = 6)
         const TileGeom t = ctx_geom(c);
         const int fb = flat_blocks(c->count / t.vec, c->flat_blocks_opt);
         double *p0;
@@ -1761,7 +1764,7 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
             else hipLaunchKernelGGL(cg::k_dot_partial<1>, dim3(fb), dim3(kBlock), 0, s, c->g, c->g, c->count, p0);
             HIPCHK(hipGetLastError());
         }
-        CGCHK(enqueue_dot_finish(c, c->g, c->g, p0, fb, 2, rtol));
+        CGCHK(enqueue_dot_finish(c, c->g, c->g, p0, fb, cont ? 6 : 2, rtol));
     }
     const int dcur_start = c->dcur, gcur_start = c->gcur, pend_start = c->lean_pending;
     long launched = 0;

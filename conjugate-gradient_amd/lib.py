@@ -21,6 +21,7 @@ OPT_PREFETCH_READ = 11
 OPT_STRICT_BLOCKS = 12
 OPT_OVERLAP = 13
 OPT_COMM_REHEARSAL = 14
+OPT_RESUM_Q0 = 19
 OPT_STRICT_SPEC = 15
 OPT_STRICT_MISSES = 16
 OPT_STRICT_EVENTS = 17

@@ -180,6 +180,9 @@ typedef struct cg_ctx cg_ctx;
                                   plain hierarchical one; cg_get_option returns the failures counted so far (must be 0) */
 #define CG_OPT_OVERLAP     13  /* several ranks, lean schedule: 1 (default) = the new gradient's boundary rows travel on a
                                   second stream while the rows between them are computed; 0 = exchange in line */
+#define CG_OPT_RESUM_Q0    19  /* 1 = a cg_solve that continues the previous one (see cg_solve) still begins with the dot
+                                  product q0 = g.g of cg.c:55 instead of taking q1 over: the reference's timed region
+                                  (cg.c:50-55) with warm vectors.  Strict order: the same bits either way.  Default 0 */
 #define CG_OPT_COMM_REHEARSAL 14 /* single-rank context with cg_comm_init: 1 = issue the per-iteration traffic of a
                                   multi-rank solve anyway (a grouped send/receive of two rows to the rank itself, the
                                   two all-gathers of the partial sums), to put a number on its cost with one GPU */
@@ -250,7 +253,12 @@ int cg_get_history(cg_ctx *ctx, double *host_dst, long count, long *written);
 /* ---- measurement ----------------------------------------------------------
  * Time `reps` back-to-back launches of one hot-path kernel of the context's
  * current schedule with HIP events on the context's own stream.
- * which: 0 = stencil kernel (as scheduled: with the fused d-update if any),
+ * which, for the default LEAN schedule (with CG_REDUCE_STRICT the passes also form their span sums):
+ *        0 = pass 1 (reads d, g; d.q),            16 B/point
+ *        1 = pass 2 (reads d, g; writes d', g'),  32 B/point
+ *        2 = pass 2 with the paired u update,     48 B/point;
+ * for CLASSIC / FUSED / FUSED_NOQ:
+ *        0 = stencil kernel (as scheduled: with the fused d-update if any),
  *        1 = update kernel, 2 = d-update kernel (CLASSIC only).
  * Outputs the mean milliseconds per launch and the algorithmic bytes one
  * launch moves (the per-point figure of the schedule times the block's points).

@@ -308,6 +308,34 @@ def test_many_short_solves_equal_one_long_solve_bitwise(cg, order):
         assert np.array_equal(bits(many.vector(which)), bits(one.vector(which))), which
 
 
+@pytest.mark.parametrize("n", [255, 1023])            # 1023: span sums formed in the passes
+def test_continuing_solve_that_sums_q0_again_keeps_the_bits(cg, n):
+    # the benchmark's timed region: a continuing solve that still begins with q0 = g.g (cg.c:55), with and without
+    # the owed updates applied in between; in the reference's summation order that dot product returns the q1 already
+    # on the device, so the bits of one long solve must come out, at every parity of the seams
+    one = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT).init_problem()
+    one.solve(40)
+    many = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT).init_problem()
+    many.set_option(cg.lib.OPT_RESUM_Q0, 1)
+    hist = []
+    for k, sync in ((5, True), (6, True), (1, False), (7, False), (2, True), (12, False), (7, True)):
+        r = many.solve(k)
+        assert r.iters == k
+        hist.append(many.history(k))
+        if sync:
+            many.sync_vectors()
+    assert float(r.q1).hex() == float(one.history(40)[-1]).hex()
+    assert np.array_equal(bits(np.concatenate(hist)), bits(one.history(40)))
+    for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+        assert np.array_equal(bits(many.vector(which)), bits(one.vector(which))), which
+    # fast order: the stand-alone dot product has its own (documented) order, so only closeness is promised
+    f = cg.CGSolver(n).init_problem()
+    f.set_option(cg.lib.OPT_RESUM_Q0, 1)
+    f.solve(20); f.sync_vectors()
+    rf = f.solve(20)
+    assert abs(rf.q1 - r.q1) <= 1e-6 * r.q1
+
+
 def test_time_kernel_leaves_the_context_unusable_until_reinitialised(cg):
     s = cg.CGSolver(255).init_problem()
     s.solve(5)
