@@ -371,20 +371,22 @@ constexpr int kSub = 128;
 // the tiled kernels 20-35 % of their time).
 // gsum != nullptr: the pass over the groups (k_xs_gsum) is done here as well -- thread t of a workgroup holds chunk
 // 256 b + t, so each of its four wavefronts holds one whole group.
+// span, stride: the sums are of `span` products each (kSub, or cg::kUnit for the records of the speculative
+// path, by rows only) and lie `stride` doubles apart (4: the first member of each record).
 __global__ __launch_bounds__(256) void k_xs_from_sub(const double *__restrict__ sub, long nsub, long nchunks,
                                                      long G, long rows, double *__restrict__ approx,
-                                                     double *__restrict__ gsum)
+                                                     double *__restrict__ gsum, int span = kSub, int stride = 1)
 {
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
     double acc = 0.0;
     if (c < nchunks) {
-#pragma unroll
-        for (int j = 0; j < kChunk / kSub; ++j) {
-            const long i = c * (kChunk / kSub) + j;
+        const int per = kChunk / span;
+        for (int j = 0; j < per; ++j) {
+            const long i = c * per + j;
             if (i >= nsub) break;
             if (G > 0) {
-                const long k = i * kSub, m = k / G, col = k - m * G;
-                acc += sub[(col / kSub) * rows + m];
+                const long k = i * span, m = k / G, col = k - m * G;
+                acc += sub[((col / span) * rows + m) * stride];
             } else {
                 acc += sub[i];
             }
@@ -538,26 +540,26 @@ __global__ __launch_bounds__(256) void k_xs_chunk(const double *__restrict__ v, 
     }
 }
 
-// ---- B': chunk summaries from the speculative span sums of the producing kernel --------------------
-// The tiled kernels of the lean schedule (cg_kernels.hpp, NH = 2) summarise every span of kSub products
-// under two hypothesised exponents e0, e0+1 while they produce them, so that the products need neither be
-// stored nor read again.  Here the real guess -- the approximate prefix sum at the span's start, known
-// only now -- picks the hypothesis that matches it; a chunk with a span for which neither does is put on
-// the repair list and summarised from recomputed products by k_sp_fix.  The span sums carry no running
+// ---- B': chunk summaries from the speculative unit sums of the producing kernel --------------------
+// The tiled kernels of the lean schedule (cg_kernels.hpp, NH = 2) summarise every unit of cg::kUnit products (one
+// workgroup's part of a row) under two hypothesised exponents e0, e0+1 while they produce them, so that the products
+// need neither be stored nor read again.  Here the real guess -- the approximate prefix sum at the unit's start, known
+// only now -- picks the hypothesis that matches it; a chunk with a unit for which neither does is put on
+// the repair list and summarised from recomputed products by k_sp_fix.  The unit sums carry no running
 // extremes; -N and +P (the sums of the negative and of the positive rounded products) bound the running
 // value from below and above whatever the order, which only makes the walk descend a little more often
-// next to a binade boundary.  The same pass writes the next iteration's hypotheses: the lower of the two
-// binades nearest to this iteration's prefix sum at the span.
+// next to a binade boundary.  The same pass writes the next iteration's hypotheses: this iteration's prefix sum at
+// the unit.
 // One wavefront per 64 rows of one chunk column (G is a multiple of kChunk here): lane = row, so every
-// access to the by-rows span arrays is a coalesced 512-byte segment.
-__global__ __launch_bounds__(256) void k_sp_select(const double *__restrict__ sub, const double *__restrict__ D0,
-                                                   const double *__restrict__ Q0, const double *__restrict__ D1,
+// access to the by-rows unit arrays is a run of consecutive records.
+struct UnitRec { double sub, D0, D1, Q0; };
+__global__ __launch_bounds__(256) void k_sp_select(const UnitRec *__restrict__ rec, int nonneg,
                                                    double *__restrict__ hyp, double rho, const double *rho_dev, long G,
                                                    long rows, const double *__restrict__ approx,
                                                    const double *__restrict__ goff, Summary *__restrict__ chunks,
                                                    int *__restrict__ fixlist, int *__restrict__ nfix)
 {
-    constexpr int kSpans = kChunk / kSub;
+    constexpr int kUnits = kChunk / kUnit;
     if (rho_dev != nullptr) rho = *rho_dev;                     // the prediction the producing kernel scaled the hypotheses by
     const int lane = threadIdx.x & 63;
     const long ccols = G / kChunk;                              // chunks per row
@@ -571,30 +573,31 @@ __global__ __launch_bounds__(256) void k_sp_select(const double *__restrict__ su
     Summary cs = identity();
     bool miss = false;
 #pragma unroll
-    for (int j = 0; j < kSpans; ++j) {
-        const long idx = (cc * kSpans + j) * rows + m;
+    for (int j = 0; j < kUnits; ++j) {
+        const long idx = (cc * kUnits + j) * rows + m;
+        const xv2 ra = reinterpret_cast<const xv2 *>(rec + idx)[0], rb = reinterpret_cast<const xv2 *>(rec + idx)[1];
+        const double usub = ra.x, D0 = ra.y, D1 = rb.x, Q0 = nonneg ? D0 : rb.y;
         const int e = exponent_of(guess);
         const int h = hyp_exponent(hyp[idx], rho);              // what the producing kernel worked with
         const int sel = (e == kNoExp) ? -1 : e - h;
         // D under the matching hypothesis; Q bounds the sum of the magnitudes under it (e0: the kernel's bound,
         // or D itself where no product is negative; e0 + 1: each magnitude at most half as large plus 3/4)
         double D, Q;
-        if (sel == 0) { D = D0[idx]; Q = (Q0 != nullptr) ? Q0[idx] : D; }
-        else if (sel == 1) { D = D1[idx]; Q = (Q0 != nullptr) ? 0.5 * Q0[idx] + 96.0 : D; }
+        if (sel == 0) { D = D0; Q = Q0; }
+        else if (sel == 1) { D = D1; Q = nonneg ? D1 : 0.5 * Q0 + 0.75 * kUnit; }
         else { D = 0.0; Q = 0.0; miss = true; }
         Summary sp;
         sp.D = D;
-        sp.mx = (Q0 != nullptr) ? Q : D;                        // the running value never exceeds the positive part ...
-        sp.mn = (Q0 != nullptr) ? -Q : 0.0;                     // ... nor falls below minus the negative part
+        sp.mx = nonneg ? D : Q;                                 // the running value never exceeds the positive part ...
+        sp.mn = nonneg ? 0.0 : -Q;                              // ... nor falls below minus the negative part
         sp.e = e;
         // exactness of the kernel's integer sums: the magnitudes under e0 stay below 2^52 in total
-        const double cert = (Q0 != nullptr) ? Q0[idx] : D0[idx];
-        sp.bad = (!(cert < 0x1p52) || D != D) ? 1 : 0;          // D is a NaN where the span held a half-way case
+        sp.bad = (!(Q0 < 0x1p52) || D != D) ? 1 : 0;            // D is a NaN where the unit held a half-way case
         cs = compose(cs, sp);
         hyp[idx] = guess;                                       // next iteration's hypotheses start from this prefix sum
-        guess += sub[idx];
+        guess += usub;
     }
-    // The bounds above ignore the order of the products inside a span.  Where products of both signs nearly cancel
+    // The bounds above ignore the order of the products inside a unit.  Where products of both signs nearly cancel
     // they are far wider than the true extremes of the running value, and every chunk within that distance of a
     // binade boundary would send the walk down to the elements.  Judged by the guess (good to a part in 1e12; the
     // margin is a part in 1e8 of the binade), a chunk that does not clearly stay inside its binade is summarised
@@ -1347,8 +1350,8 @@ struct Workspace {
     long cap_chunks = 0;
     // speculative path (reserve_spec): span sums under two hypotheses, the hypotheses of the two dot products of
     // an iteration (they persist from one iteration to the next), the repair list
-    double *spD0 = nullptr, *spQ0 = nullptr, *spD1 = nullptr;
-    double *hyp[2] = {nullptr, nullptr};              // last iteration's prefix sum at every span (0 = none yet)
+    double *rec = nullptr;                            // one record of four doubles per unit of cg::kUnit products (UnitRec)
+    double *hyp[2] = {nullptr, nullptr};              // last iteration's prefix sum at every unit (0 = none yet)
     int *fixlist = nullptr, *nfix = nullptr;
     long cap_spec = 0;
 
@@ -1386,10 +1389,9 @@ struct Workspace {
         const long nc = chunks_for(count);
         if (nc <= cap_spec) return hipSuccess;
         release_spec();
-        const size_t nspan = (size_t)nc * (kChunk / kSub);
+        const size_t nspan = (size_t)nc * (kChunk / kUnit);
         hipError_t e;
-        for (double **p : {&spD0, &spQ0, &spD1})
-            if ((e = hipMalloc(p, nspan * sizeof(double))) != hipSuccess) return e;
+        if ((e = hipMalloc(&rec, 4 * nspan * sizeof(double))) != hipSuccess) return e;
         for (int k = 0; k < 2; ++k) {
             if ((e = hipMalloc(&hyp[k], nspan * sizeof(double))) != hipSuccess) return e;
             if ((e = hipMemset(hyp[k], 0, nspan * sizeof(double))) != hipSuccess) return e;
@@ -1404,15 +1406,15 @@ struct Workspace {
     void forget_hypotheses()                              // a new problem: last solve's prefix sums say nothing about it
     {
         if (cap_spec == 0) return;
-        const size_t nspan = (size_t)cap_spec * (kChunk / kSub);
+        const size_t nspan = (size_t)cap_spec * (kChunk / kUnit);
         for (int k = 0; k < 2; ++k) (void)hipMemset(hyp[k], 0, nspan * sizeof(double));
         (void)hipDeviceSynchronize();
     }
     void release_spec()
     {
-        (void)hipFree(spD0); (void)hipFree(spQ0); (void)hipFree(spD1);
+        (void)hipFree(rec);
         (void)hipFree(hyp[0]); (void)hipFree(hyp[1]); (void)hipFree(fixlist); (void)hipFree(nfix);
-        spD0 = spQ0 = spD1 = nullptr; hyp[0] = hyp[1] = nullptr; fixlist = nullptr; nfix = nullptr;
+        rec = nullptr; hyp[0] = hyp[1] = nullptr; fixlist = nullptr; nfix = nullptr;
         cap_spec = 0;
     }
     void release()
@@ -1460,8 +1462,8 @@ inline void enqueue_approx(hipStream_t s, const Workspace &ws, const Arrays &a, 
     const long nc = Workspace::chunks_for(a.count);
     const long ng = (nc + kGroup - 1) / kGroup;
     if (a.have_sub) {
-        hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub,
-                           (a.count + kSub - 1) / kSub, nc, a.sub_G, a.sub_rows, ws.approx, ws.goff);
+        hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (const double *)ws.sub,
+                           (a.count + kSub - 1) / kSub, nc, a.sub_G, a.sub_rows, ws.approx, ws.goff, (int)kSub, 1);
     } else {
         hipLaunchKernelGGL(k_xs_approx, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, s, a.v, a.w, a.count, nc, a.vec(), ws.approx);
         hipLaunchKernelGGL(k_xs_gsum, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.approx, nc, ws.goff, ng);
@@ -1534,8 +1536,8 @@ inline void spec_approx(hipStream_t s, const Workspace &ws, long G, long rows, d
     const long count = G * rows;
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ws.sub, (count + kSub - 1) / kSub,
-                       nc, G, rows, ws.approx, ws.goff);
+    hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (const double *)ws.rec, count / kUnit,
+                       nc, G, rows, ws.approx, ws.goff, (int)kUnit, 4);
     if (total_out) hipLaunchKernelGGL(k_xs_total, dim3(1), dim3(1024), 0, s, ws.goff, ng, total_out);
 }
 
@@ -1548,8 +1550,8 @@ inline void spec_summaries(hipStream_t s, const Workspace &ws, const Src &src, l
     const long ng = (nc + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, seed_dev, nseed, ws.nfix);
     const long nwave = ((rows + 63) / 64) * (G / kChunk);
-    hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, ws.sub, ws.spD0,
-                       nonneg ? (const double *)nullptr : ws.spQ0, ws.spD1, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
+    hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const UnitRec *>(ws.rec),
+                       nonneg ? 1 : 0, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
     hipLaunchKernelGGL(k_sp_fix<Src>, dim3(256), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
     enqueue_levels_and_plan(s, ws, src, count);
 }

@@ -177,15 +177,17 @@ struct StencilArgs {
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
     Coef9 coef;                       // stencil coefficients
     int store_products;               // WRITE_Q kernels: store d*q (rounded) where q would go
-    // Strict order, speculative summaries (kernels instantiated with NH = 2 only; all arrays in the layout of `sub`):
-    // hyp[span] is last iteration's prefix sum at the span; scaled by the predicted growth sc->rho[hyp_which] it
-    // gives the LOWER of two hypotheses e0, e0+1 (hyp_exponent) for the exponent of the sequential sum when it
-    // reaches the span; the kernel stores, for each hypothesis, the sum D of the span's products rounded to that
-    // binade's ulp (in ulps), and for e0 an upper bound Q0 of the sum of their magnitudes (a NaN D marks a span
-    // with a half-way case).
+    // Strict order, speculative summaries (kernels instantiated with NH = 2 only).  The unit is one workgroup's part
+    // of a row, kUnit = 512 consecutive products; unit (strip, row r) has index strip * rows + r.  hyp[unit] is last
+    // iteration's prefix sum at the unit; scaled by the predicted growth sc->rho[hyp_which] it gives the LOWER of two
+    // hypotheses e0, e0+1 (hyp_exponent) for the exponent of the sequential sum when it reaches the unit.  The kernel
+    // stores one record of four doubles per unit in rec[4 * unit ...]: the plain sum of the unit's products (the
+    // approximate sum), for each hypothesis the sum D of the products rounded to that binade's ulp (in ulps; a NaN
+    // marks a unit with a half-way case), and for e0 an upper bound Q0 of the sum of their magnitudes (not written
+    // where every product is >= 0, g.g: Q = D there).
     const double *hyp;
     int hyp_which;                    // 0 = d.q, 1 = g.g
-    double *spD0, *spQ0, *spD1;       // spQ0 is not written when every product is >= 0 (g.g): Q = D there
+    double *rec;
     double *sub;                      // VEC 2 and G % 128 == 0, or nullptr: sum of the products d.q of
                                       // (MODE 2, 4, 5: g.g) of every aligned 128-element span (one wavefront's part of a
                                       // row), at sub[(column/128)*rows + r] -- approximate sums for the strict-order dot
@@ -363,7 +365,7 @@ struct RawRow {
 // that hypothesis' D into a NaN.
 // The sums over the 64 lanes are NOT formed row by row (four dependent data-parallel reductions per row cost
 // more than the rest of the pass): the entries of four consecutive rows are reduced together through LDS
-// (span4_push_lds), those of eight in registers, the lanes trading rows (span8_push).
+// (span4_push_lds), and the four wavefronts' sums are added to one record per workgroup and row (unit_combine).
 struct SpanEntry {
     double sub, D0, D1;
     float qf;
@@ -391,12 +393,7 @@ __device__ __forceinline__ SpanEntry span_entry(const double (&p)[VEC], int e0, 
     return s;
 }
 
-// ---- eight rows at once -----------------------------------------------------------------------------------
-// The read-only pass holds the entries of eight consecutive rows in registers, and eight sums over the wavefront
-// need not cost eight reductions: halves of the wavefront trade rows (each keeps four rows and receives the other
-// half's contributions to them), then quarters, then eighths, and what is left is one sum over eight lanes --
-// v[p] of lane l ends up, summed over all lanes, in the eight lanes 8p .. 8p+7.  34 instructions per quantity
-// for the eight rows, against 8 x 18 when each row is reduced by itself.
+// lanes trade halves (32 lanes) or rows of 16 lanes and add: the last two steps of a sum over the wavefront
 __device__ __forceinline__ void swap_add32(double &a, double b)     // a <- [a.lower + a.upper | b.lower + b.upper]  (halves of 32 lanes)
 {
     const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
@@ -409,113 +406,27 @@ __device__ __forceinline__ void swap_add16(double &a, double b)     // rows of 1
     const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
     a = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
-template <int CTRL> __device__ __forceinline__ double dpp_move(double v)
-{
-    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true),
-                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
-}
-// v[p], p = 0..7, summed over the wavefront (in no particular order); the sum of v[p] is returned in lanes 8p .. 8p+7.
-__device__ __forceinline__ double wave_sum8(double (&v)[8])
-{
-    const bool upper = (threadIdx.x & 8) != 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) swap_add32(v[p], v[p + 4]);          // lanes 0..31: rows 0..3, lanes 32..63: rows 4..7
-    swap_add16(v[0], v[2]);                                          // rows of 16 lanes now hold rows 0, 2, 4, 6 ...
-    swap_add16(v[1], v[3]);                                          // ... and 1, 3, 5, 7
-    const double keep = upper ? v[1] : v[0], give = upper ? v[0] : v[1];
-    double y = keep + dpp_move<0x128>(give);                              // row_ror:8 -- eight lanes per row
-    y += dpp_move<0xB1>(y);                                          // quad_perm [1,0,3,2]
-    y += dpp_move<0x4E>(y);                                          // quad_perm [2,3,0,1]
-    y += dpp_move<0x141>(y);                                         // row_half_mirror: the other quad of the eight
-    return y;
-}
 
-// The same tree taken as the rows arrive, so that at most three partly reduced quadruples are alive at a time
-// (entries of rows 2i and 2i+1 trade halves as soon as the second exists, pairs of those trade quarters, ...):
-// what a wavefront contributes to the four span arrays for one row, and its partial reductions.
-struct SpanQuad {
-    double su, d0, d1, q;
-};
-template <bool NONNEG>
-__device__ __forceinline__ SpanQuad quad_swap32(SpanQuad a, const SpanQuad &b)
-{
-    swap_add32(a.su, b.su); swap_add32(a.d0, b.d0); swap_add32(a.d1, b.d1);
-    if (!NONNEG) swap_add32(a.q, b.q);
-    return a;
-}
-template <bool NONNEG>
-__device__ __forceinline__ SpanQuad quad_swap16(SpanQuad a, const SpanQuad &b)
-{
-    swap_add16(a.su, b.su); swap_add16(a.d0, b.d0); swap_add16(a.d1, b.d1);
-    if (!NONNEG) swap_add16(a.q, b.q);
-    return a;
-}
-__device__ __forceinline__ double eight_finish(double x0, double x1)
-{
-    const bool upper = (threadIdx.x & 8) != 0;
-    const double keep = upper ? x1 : x0, give = upper ? x0 : x1;
-    double y = keep + dpp_move<0x128>(give);
-    y += dpp_move<0xB1>(y);
-    y += dpp_move<0x4E>(y);
-    y += dpp_move<0x141>(y);
-    return y;
-}
-struct Span8 {
-    SpanQuad pend, wpend, xpend;
-};
-// Row number P (0..7, a constant once the row loop is unrolled) of a batch of eight that begins at row m0: a
-// row with a half-way case gets a NaN for that hypothesis' D (planted in the lane that saw it, it travels through
-// the sums).  After row 7 the eight lanes 8k .. 8k+7 hold the sums of row bitrev3(k), and lane 8k stores them (rows
-// in [m_lo, m_hi) only).
-template <bool NONNEG>
-__device__ __forceinline__ void span8_push(Span8 &st, int P, const SpanEntry &e, bool t0, bool t1, long m0, long m_lo, long m_hi,
-                                           long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
-{
-    SpanQuad cur;
-    cur.su = e.sub;
-    cur.d0 = t0 ? __builtin_nan("") : e.D0;
-    cur.d1 = t1 ? __builtin_nan("") : e.D1;
-    cur.q = NONNEG ? 0.0 : (double)e.qf;
-    if ((P & 1) == 0) {
-        st.pend = cur;
-    } else {
-        const SpanQuad w = quad_swap32<NONNEG>(st.pend, cur);
-        if ((P & 2) == 0) {
-            st.wpend = w;
-        } else {
-            const SpanQuad x = quad_swap16<NONNEG>(st.wpend, w);
-            if ((P & 4) == 0) {
-                st.xpend = x;
-            } else {
-                const double rs = eight_finish(st.xpend.su, x.su), r0 = eight_finish(st.xpend.d0, x.d0),
-                             r1 = eight_finish(st.xpend.d1, x.d1);
-                double rq = 0.0;
-                if (!NONNEG) rq = eight_finish(st.xpend.q, x.q);
-                const int lane = threadIdx.x & 63, k = lane >> 3;
-                const long m = m0 + (((k & 1) << 2) | (k & 2) | (k >> 2));
-                if ((lane & 7) == 0 && m >= m_lo && m < m_hi) {
-                    sub[span_col + m] = rs;
-                    spD0[span_col + m] = r0;
-                    spD1[span_col + m] = r1;
-                    if (!NONNEG) spQ0[span_col + m] = rq * (1.0 + 0x1p-12) + 1.0;
-                }
-            }
-        }
-    }
-}
-
-// Batches of four rows through LDS (kernels that keep fewer than eight rows in flight): every lane parks its
-// entries of the four rows in its wavefront's own LDS block -- quantity-and-row major, one double per lane, so the
-// stores are conflict-free and nothing is held in registers between rows -- and after the fourth row lane
-// 16*part + j adds up sixteen lanes' worth of quantity-and-row j; two swaps between halves and quarters of the
-// wavefront finish the sums, and lanes 0..15 store them: four consecutive rows of each span array.  About 60
-// instructions per batch against 130 for the exchange in registers; the sums are of integers (or approximate by
-// design), so their order is free.
+// Batches of four rows through LDS: every lane parks its entries of the four rows in its wavefront's own LDS block
+// -- quantity-and-row major, one double per lane, so the stores are conflict-free and nothing is held in registers
+// between rows -- and after the fourth row lane 16*part + j adds up sixteen lanes' worth of quantity-and-row j; two
+// swaps between halves and quarters of the wavefront finish the sums (about 60 instructions per batch; the sums are of
+// integers, or approximate by design, so their order is free).  Lanes 0..15 then hold the wavefront's sixteen sums and
+// leave them in the workgroup's exchange block X; wavefront 0 adds the four wavefronts' sums to the unit's (the
+// workgroup's 512 products of the row) one row later, behind the row's barrier (unit_combine).
+//
+// Nothing goes to memory row by row: a store sits in the wavefront's vector-memory queue in issue order with the
+// loads, which retire in order, so every wait for a prefetched row behind it also waits for the store to be
+// acknowledged -- and small writes trickling into a read stream cost the memory system far more than their bytes.
+// (Measured at 16384^2, read-only pass: 0.91 ms with a 16-lane store of four 32-byte pieces per wavefront every four
+// rows, 0.69 ms without any store, 0.64 in the fast order.)  The unit records are staged in LDS, 256 rows at a time
+// (aligned in the row number), and written by wavefront 0 in one contiguous run of 8 KiB per window.
 constexpr int kSpanStride = 65;                        // doubles per quantity-and-row in the LDS block (64 lanes + 1: the reads of the four parts fall on different banks)
 constexpr int kSpanLds = 16 * kSpanStride;             // doubles per wavefront
+constexpr int kUnitWindow = 256;                       // rows of unit records staged before they are written
+constexpr int kUnitLds = kWaves * 16 + 4 * kUnitWindow; // doubles per workgroup: the exchange block X, then the staged records
 template <bool NONNEG>
-__device__ __forceinline__ void span4_push_lds(double *R, int P, const SpanEntry &e, bool t0, bool t1, long m0, long m_lo,
-                                               long m_hi, long span_col, double *sub, double *spD0, double *spQ0, double *spD1)
+__device__ __forceinline__ void span4_push_lds(double *R, double *X, int P, const SpanEntry &e, bool t0, bool t1)
 {
     const int lane = threadIdx.x & 63;
     R[(0 + P) * kSpanStride + lane] = e.sub;
@@ -538,15 +449,44 @@ __device__ __forceinline__ void span4_push_lds(double *R, int P, const SpanEntry
         double y = v[0];
         swap_add16(y, y);                               // every row of 16 lanes: its own part plus its neighbour's
         swap_add32(y, y);                               // ... plus the other half's pair
-        const int q = j >> 2;
-        const long m = m0 + (j & 3);
-        double *arr = (q == 0) ? sub : (q == 1) ? spD0 : (q == 2) ? spD1 : spQ0;
-        if (q == 3) y = y * (1.0 + 0x1p-12) + 1.0;
-        if (lane < (NONNEG ? 12 : 16) && m >= m_lo && m < m_hi) arr[span_col + m] = y;
+        if ((j >> 2) == 3) y = y * (1.0 + 0x1p-12) + 1.0;       // the bound Q: above the rounding of its single-precision parts
+        if (lane < 16) X[(threadIdx.x >> 6) * 16 + lane] = (NONNEG && lane >= 12) ? 0.0 : y;   // [quantity][row of the batch]
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // all reads done before the block's next use
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// Wavefront 0, one row after a batch was parked (the row's barrier lies in between): the four wavefronts' sums of the
+// batch whose first row is m0 (a multiple of four) added to unit sums and staged; a complete window of kUnitWindow rows
+// (or, with `last`, whatever the tile's last window holds) goes to the records of rows [m_lo, m_hi) at rec_col =
+// rec + 4 * (first unit of this strip).  X and S: the workgroup's exchange and staging blocks.
+__device__ __forceinline__ void unit_combine(const double *X, double *S, int m0, bool last, int m_lo, int m_hi, double *rec_col)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < 16) {
+        const double y = (X[lane] + X[16 + lane]) + (X[32 + lane] + X[48 + lane]);
+        S[((m0 & (kUnitWindow - 1)) + (lane & 3)) * 4 + (lane >> 2)] = y;
+    }
+    const bool full = (m0 & (kUnitWindow - 1)) == kUnitWindow - 4;
+    if (!full && !last) return;
+    const int wbase = m0 & ~(kUnitWindow - 1);
+    if (wbase + kUnitWindow <= m_lo) return;            // a window above the tile (the rows before its first one)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    v2d *dst = reinterpret_cast<v2d *>(rec_col + (long)wbase * 4);
+#pragma unroll
+    for (int i = 0; i < 4 * kUnitWindow / 128; ++i) {
+        const int pair = i * 64 + lane;                 // two doubles: half a record
+        const int m = wbase + (pair >> 1);
+        const v2d v = reinterpret_cast<const v2d *>(S)[pair];
+        if (m >= m_lo && m < m_hi) __builtin_nontemporal_store(v, dst + pair);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // all reads done before the window's next use
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kUnit = 512;            // products per unit of the speculative summaries: one workgroup's part of a row (VEC = 2)
 
 constexpr int kHypNone = -30000;      // "no hypothesis": every non-zero product overflows under it, the span is redone later
 
@@ -577,7 +517,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     if (a.sc != nullptr && a.sc->done) return;
 
     __shared__ double row_lds[2][W + 2];
-    __shared__ double span_lds[(NH > 0) ? kWaves * kSpanLds : 1];
+    __shared__ __attribute__((aligned(16))) double span_lds[(NH > 0) ? kWaves * kSpanLds + kUnitLds : 2];
+    static_assert(NH == 0 || (CONTIG && VEC == 2 && PF <= 4), "the span sums need the context's layout, 16-byte rows and batches of four rows");
     __shared__ double wave_slots[kWaves];
     const int tid = threadIdx.x;
     const long nwg = (long)gridDim.x;
@@ -613,9 +554,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     }
 
     // NH > 0: this wavefront's column of the span arrays (span index = column block * rows + row)
-    const long span_col = (NH > 0) ? ((c0 >> 7) + __builtin_amdgcn_readfirstlane(tid >> 6)) * a.rows : 0;
+    // NH > 0: this strip's column of the unit arrays (unit index = strip * rows + row)
+    const long unit_col = (NH > 0) ? strip * a.rows : 0;
     const __amdgpu_buffer_rsrc_t hyp_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>((NH > 0) ? a.hyp + span_col : nullptr), 0,
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>((NH > 0) ? a.hyp + unit_col : nullptr), 0,
                                           (NH > 0) ? (int)(a.rows * 8) : 0, kRsrcFlags);
     const double rho = (NH > 0) ? a.sc->rho[a.hyp_which] : 1.0;
 
@@ -688,18 +630,22 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     double acc = 0.0, acc2 = 0.0;
     double mid_hyp = 0.0;
 
+    // NH > 0: the span sums of four rows are reduced over the wavefront together (span4_push_lds); a kernel that keeps
+    // fewer than four rows in flight goes through its ring twice or four times per batch.  Batches begin at a multiple
+    // of four rows, so that 64 of them fill an aligned window of the staged records; the up to three extra rows above
+    // the tile's upper halo fail the range check like any row outside the tile.
+    constexpr int BATCH = (NH > 0) ? 4 : PF;
+    const int rb0 = (NH > 0) ? (((r0 - 2) & ~3) + 1) : (r0 - 1);
+    double *const span_R = span_lds + (tid >> 6) * kSpanLds, *const span_X = span_lds + kWaves * kSpanLds, *const span_S = span_X + kWaves * 16;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     RawRow<VEC> ring[PF];
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load_row(r0 - 1 + p, ring[p]);
+    for (int p = 0; p < PF; ++p) load_row(rb0 + p, ring[p]);
     int buf = 0;
     // Rows r0-1 .. r1 in groups of PF; a group may run past r1, those rows are fully
     // masked (zero loads, dropped stores, zero contributions to the partial sum).
-    // NH > 0: the span sums of a batch of four or eight rows are reduced over the wavefront together (span4_push_lds,
-    // span8_push); a kernel that keeps fewer than four rows in flight goes through its ring twice or four times per batch.
-    constexpr int BATCH = (NH > 0 && PF < 4) ? 4 : PF;
-    static_assert(NH == 0 || BATCH == 4 || BATCH == 8, "the span sums are reduced in batches of four or eight rows");
-    for (int rb = r0 - 1; rb <= r1; rb += BATCH) {
-        Span8 span8;
+    int rb = rb0;
+    for (; rb <= r1; rb += BATCH) {
 #pragma unroll
         for (int p = 0; p < BATCH; ++p) {
             const int r = rb + p;
@@ -715,7 +661,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                 // halo) is kept up to date locally, so that only g has to travel.
                 if (!STORE_D) {
                 } else if (CONTIG) {
-                    const bool wr = (r >= r0 && r < r1) || (r < 0 && a.d_top_out != nullptr) ||
+                    const bool wr = (r >= r0 && r < r1) || (r == -1 && a.d_top_out != nullptr) ||
                                     (r >= nrows && r <= r1 && a.d_bot_out != nullptr);
                     BufIO<VEC>::store(row_rsrc_nn(a.d_out + (long)r * G, wr ? rowbytes : 0), off_main, cur);
                 } else {
@@ -741,6 +687,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
             const double curL = L[tid * VEC];
             const double curR = L[tid * VEC + VEC + 1];
             buf ^= 1;
+            // the batch parked one row ago (the barrier above lies in between): its unit sums, staged
+            if (NH > 0 && p == 0 && VEC == 2 && a.sub != nullptr && rb > rb0 && wave0)
+                unit_combine(span_X, span_S, rb - 5, false, r0, r1, a.rec + 4 * unit_col);
 
             // Rows r-2 (up), r-1 (mid) and r (cur) are now in registers: emit row r-1.
             const int m = r - 1;
@@ -799,8 +748,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                     } else {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                        if (BATCH == 8) span8_push<true>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                        else span4_push_lds<true>(span_lds + (tid >> 6) * kSpanLds, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        span4_push_lds<true>(span_R, span_X, p, e, t0, t1);
                     }
                 }
                 if (MODE == 5) {
@@ -828,8 +776,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                     } else {
                         bool t0, t1;
                         const SpanEntry e = span_entry<VEC, false>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
-                        if (BATCH == 8) span8_push<false>(span8, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
-                        else span4_push_lds<false>(span_lds + (tid >> 6) * kSpanLds, p, e, t0, t1, rb - 1, r0, r1, span_col, a.sub, a.spD0, a.spQ0, a.spD1);
+                        span4_push_lds<false>(span_R, span_X, p, e, t0, t1);
                     }
                 }
                 if (WRITE_Q) {
@@ -854,6 +801,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
             upL = midL; upR = midR;
             midL = curL; midR = curR;
         }
+    }
+    if (NH > 0 && VEC == 2 && a.sub != nullptr) {          // the last batch (its first row: rb - 5), and the tile's last window of records
+        lds_barrier();
+        if (wave0) unit_combine(span_X, span_S, rb - 5, true, r0, r1, a.rec + 4 * unit_col);
     }
 
     const double s = block_sum(acc, wave_slots);

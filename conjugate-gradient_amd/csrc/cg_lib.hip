@@ -208,11 +208,10 @@ long launch_stencil(const TileGeom &t, const StencilArgs &a0, hipStream_t s, lon
     const long nwg = (cap > 0 && cap < a.ntiles_launch) ? cap : a.ntiles_launch;
     const dim3 grid((unsigned)nwg), block(kBlock);
 #define CG_LAUNCH(V, P, C) hipLaunchKernelGGL((cg::k_stencil<V, MODE, WRITE_Q, P, C, NH>), grid, block, 0, s, a)
-    if (NH > 0) {                     // speculative strict summaries: 16-byte rows in the context's layout only
+    if constexpr (NH > 0) {           // speculative strict summaries: 16-byte rows in the context's layout only
         switch (MODE == 3 ? t.pf_spec_read : (MODE == 5 ? t.pf_spec_u : t.pf_mode[MODE])) {
         case 1: CG_LAUNCH(2, 1, true); break;
-        case 4: CG_LAUNCH(2, 4, true); break;
-        case 8: CG_LAUNCH(2, 8, true); break;
+        case 4: case 8: CG_LAUNCH(2, 4, true); break;      // at most four rows in flight with the span sums
         default: CG_LAUNCH(2, 2, true); break;
         }
     } else if (!t.contig) {                  // stand-alone entry point: caller-supplied halo pointers
@@ -650,7 +649,7 @@ int enqueue_lean_iteration(cg_ctx *c)
     double *const sub = strict_sub(c, t);
     const bool spec = strict && strict_speculative(c, t);
     a.sub = sub;
-    a.spD0 = c->xs.spD0; a.spQ0 = c->xs.spQ0; a.spD1 = c->xs.spD1;
+    a.rec = c->xs.rec;
     if (spec) {
         a.hyp = c->xs.hyp[0]; a.hyp_which = 0;
         a.partials2 = c->partials + 2 * c->npart;
@@ -1902,7 +1901,7 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
             const int out = c->dcur ^ 1;
             a.partials = c->partials; a.d_in = c->d[c->dcur]; a.g = c->g;
             if (spec) {                                    // strict order: the passes with their span summaries
-                a.sub = c->xs.sub; a.spD0 = c->xs.spD0; a.spQ0 = c->xs.spQ0; a.spD1 = c->xs.spD1;
+                a.sub = c->xs.sub; a.rec = c->xs.rec;
                 a.hyp = c->xs.hyp[which == 0 ? 0 : 1]; a.hyp_which = which == 0 ? 0 : 1;
                 a.partials2 = c->partials + 2 * c->npart;
             }
