@@ -306,6 +306,8 @@ struct cg_ctx {
     bool live = false;                    // q0 / beta on the device belong to the vectors' present state: a
                                           // solve may continue from them without summing g.g again
     bool needs_init = false;              // cg_time_kernel ran: the vectors are scratch until cg_init_problem
+    bool d_halo_stale = false;            // several ranks: d[dcur] changed after its boundary rows last travelled (the classic
+                                          // schedule exchanges them at the start of an iteration and updates d at its end)
 
     // halo rows (multi-GPU).  *_top = the row above the block, *_bot = below.
     double *halo_d[kMaxSlots][2] = {{nullptr, nullptr}};               // [buffer][top/bot]
@@ -798,8 +800,13 @@ int enqueue_iteration(cg_ctx *c, bool first)
                                                         c->halo_d[c->dcur][1])));
             }
         }
-        // (first iteration of a fused schedule: d's halo rows are current -- a closed form at set-up,
-        //  exchanged when a pending d update was applied)
+        // First iteration of a fused schedule: d's halo rows are current -- a closed form at set-up, exchanged
+        // when a pending d update was applied -- unless a classic solve ran last, which leaves them one d update
+        // behind: then they travel once more.
+        if (first && sched != CG_SCHED_CLASSIC && c->nranks > 1 && c->d_halo_stale) {
+            CGCHK(comm_rc(c, c->comm->exchange_rows(s, c->d[c->dcur], c->rows, c->G, c->halo_d[c->dcur][0], c->halo_d[c->dcur][1])));
+            c->d_halo_stale = false;
+        }
     }
     if (fuse) {
         const int in = c->dcur, out = c->dcur ^ 1;
@@ -1635,6 +1642,7 @@ int cg_init_problem(cg_ctx *c)
     c->pending_dupdate = false;
     c->live = false;
     c->needs_init = false;
+    c->d_halo_stale = false;
     c->q_valid = true;
     c->xs.forget_hypotheses();
     HIPCHK(hipMemsetAsync(c->u, 0, bytes, s));           // calloc, cg.c:44
@@ -1812,6 +1820,7 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     } else {
         c->dcur = dcur_start;
         c->set_gcur(gcur_start);
+        if (c->nranks > 1 && executed >= 1) c->d_halo_stale = true;
     }
     if (c->lean_pending < 0 || c->lean_pending > 1) return fail(CG_ERR_STATE, "lean schedule: %d u updates owed", c->lean_pending);
     c->live = true;

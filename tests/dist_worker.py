@@ -64,8 +64,9 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast", digest=False):
     G = n + 1
     row0, rows = cg.dist.partition(G, tr.world, tr.rank)
     s = cg.CGSolver(n, device=0, row0=row0, rows=rows, rank=tr.rank, nranks=tr.world)
-    s.configure(schedule={"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ,
-                          "lean": cg.SCHED_LEAN}[schedule])
+    ids = {"classic": cg.SCHED_CLASSIC, "fused": cg.SCHED_FUSED, "fused_noq": cg.SCHED_FUSED_NOQ, "lean": cg.SCHED_LEAN}
+    schedule, _, second = schedule.partition(">")    # "a>b": the first solve runs schedule a, the continuation schedule b
+    s.configure(schedule=ids[schedule])
     if order != "fast":                           # one accumulator handed from rank to rank
         s.configure(reduce=cg.REDUCE_STRICT, schedule=s.schedule,
                     strict_impl={"strict": cg.STRICT_AUTO, "strict_replay": cg.STRICT_REPLAY,
@@ -79,6 +80,8 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast", digest=False):
     else:                                         # two calls: the second continues the first
         first = s.solve(iters // 2)
         h1 = s.history(iters)
+        if second:
+            s.configure(schedule=ids[second])
         r = s.solve(iters - iters // 2)
         total, hist, q_init = first.iters + r.iters, np.concatenate([h1, s.history(iters)]), first.q_init
     out = dict(row0=row0, hist=hist, q1=r.q1, iters=total, converged=int(r.converged), q_init=q_init)

@@ -70,6 +70,20 @@ def test_multirank_strict_order_reproduces_single_rank_reference_bits(golden, or
     assert np.array_equal(np.asarray(res[0]["hist"]).view(np.uint64), ref["hist"].view(np.uint64))
 
 
+@pytest.mark.parametrize("switch", ["classic>lean", "classic>fused", "classic>fused_noq", "lean>classic", "fused>lean"])
+def test_multirank_schedule_switch_between_two_solves_keeps_the_bits(oracle, tmp_path, switch):
+    # The classic schedule exchanges d's boundary rows at the start of an iteration and changes d afterwards, so
+    # the locally kept halo rows of d are stale when its solve ends; a following fused / lean solve starts with an
+    # iteration that reads them.  Strict order: every rank must hold the single-rank bits after the switch.
+    n, iters = 255, 40
+    res = run_ranks(4, ["gpu", n, iters, tmp_path, switch, 0.0, "strict"], tmp_path)
+    ref = oracle.cg(n, iters)
+    assert all(float(r["q1"]).hex() == float(ref["q1"]).hex() for r in res)
+    for k in ("u", "g", "d"):
+        assert np.array_equal(stack(res, k).view(np.uint64), ref[k].view(np.uint64)), k
+    assert np.array_equal(np.asarray(res[0]["hist"]).view(np.uint64), ref["hist"].view(np.uint64))
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_headline_grid_in_row_blocks_reproduces_the_single_rank_bits(cg, tmp_path, world):
     # 16384^2 split over 2 and 8 row blocks (8: the 2048-row blocks of an 8-GPU node), strict order: every block
