@@ -104,10 +104,13 @@ constexpr long kMaxPartials = 1 << 16;
 DeviceScratch g_scratch[kMaxDevices];
 std::mutex g_scratch_mu;
 
+int resolve_static_scratch(int device);              // the static array of cg_stencil_noalloc: address looked up while no capture can be running
+
 int get_scratch(int device, DeviceScratch **out)
 {
     CGCHK(select_device(device));
     if (device >= kMaxDevices) return fail(CG_ERR_ARG, "device index too large");
+    (void)resolve_static_scratch(device);
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     DeviceScratch &s = g_scratch[device];
     if (!s.ready) {
@@ -1258,11 +1261,28 @@ int cg_verify_u(int device, long n, long row0, long rows, const double *u, doubl
 // of memory the library allocates: nothing here calls hipMalloc, hipFree, a stream or event constructor
 // or any other allocating routine, and nothing synchronises, so the call may sit inside a stream capture.
 // Each GPU holds its own copy of the array until the process ends; its address on a device is looked up
-// once, with that device current, and only that address is ever handed to kernels.
+// once, with that device current, and only that address is ever handed to kernels.  The look-up itself
+// (which may make the runtime load the code object) is kept out of captures: every other entry point that
+// touches a device does it on the way (static_scratch_ptr from get_scratch / cg_create), and a first call on
+// a device that arrives under capture is refused.
 constexpr long kStaticPartials = 1L << 16;               // tiles of one call: 512 KiB of partial sums
 static __device__ __align__(256) double scratch[kStaticPartials];
 static double *g_static_ptr[kMaxDevices] = {nullptr};
 static std::mutex g_static_mu;
+
+// Address of `scratch` on `device` (which must be current), resolved on first use.
+static int static_scratch_ptr(int device, double **out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(CG_ERR_ARG, "device index too large");
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (!g_static_ptr[device]) {
+        void *p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_static_ptr[device] = static_cast<double *>(p);
+    }
+    if (out) *out = g_static_ptr[device];
+    return CG_OK;
+}
 
 int cg_stencil_noalloc(int device, long G, long row0, long rows, const double *d, const double *top,
                        const double *bot, double *q, double *dq_dev, void *stream)
@@ -1272,25 +1292,34 @@ int cg_stencil_noalloc(int device, long G, long row0, long rows, const double *d
         return fail(CG_ERR_ARG, "cg_stencil_noalloc: need G >= 3 and 0 <= row0 < row0+rows <= G");
     if ((row0 > 0 && !top) || (row0 + rows < G && !bot))
         return fail(CG_ERR_ARG, "cg_stencil_noalloc: a block that does not touch the global boundary needs its halo row");
-    CGCHK(select_device(device));
-    if (device >= kMaxDevices) return fail(CG_ERR_ARG, "device index too large");
+    if (device < 0 || device >= kMaxDevices) return fail(CG_ERR_ARG, "device index too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int caller_device = -1;
+    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
+    if (caller_device != device) CGCHK(select_device(device));
+    struct Restore {                                    // the caller's current device is the caller's business
+        int dev, mine;
+        ~Restore() { if (dev >= 0 && dev != mine) (void)hipSetDevice(dev); }
+    } restore{caller_device, device};
     double *ptr = nullptr;
     {
-        std::lock_guard<std::mutex> lock(g_static_mu);
-        if (!g_static_ptr[device]) {                    // once per device, that device being current
-            void *p = nullptr;
-            HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-            g_static_ptr[device] = static_cast<double *>(p);
+        bool known;
+        { std::lock_guard<std::mutex> lock(g_static_mu); known = g_static_ptr[device] != nullptr; }
+        if (!known) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+            if (st != hipStreamCaptureStatusNone)
+                return fail(CG_ERR_STATE, "cg_stencil_noalloc: the first call on a device must be made outside stream capture "
+                            "(it looks up the address of the static scratch array; any earlier library call on the device does too)");
         }
-        ptr = g_static_ptr[device];
+        CGCHK(static_scratch_ptr(device, &ptr));
     }
     const bool al = aligned16(d) && aligned16(q) && (!top || aligned16(top)) && (!bot || aligned16(bot));
     const TileGeom t = tile_geom(G, rows, al, 0);
     if (t.ntiles > kStaticPartials)
-        return fail(CG_ERR_ARG, "cg_stencil_noalloc: %ld tiles exceed the %ld the static scratch array holds "
-                    "(blocks up to about %ld points fit); use cg_stencil", t.ntiles, kStaticPartials,
-                    kStaticPartials * 512L * 16L);
-    hipStream_t s = static_cast<hipStream_t>(stream);
+        return fail(CG_ERR_ARG, "cg_stencil_noalloc: %ld tiles (%d column strips x %ld row tiles of %d rows) exceed the %ld partial "
+                    "sums the static scratch array holds; use cg_stencil", t.ntiles, t.nstrips, t.ntiles / t.nstrips, t.tile_h,
+                    kStaticPartials);
     StencilArgs a;
     memset(&a, 0, sizeof a);
     a.d_in = d; a.d_top = row0 > 0 ? top : nullptr; a.d_bot = row0 + rows < G ? bot : nullptr;
@@ -1305,6 +1334,12 @@ int cg_stencil_noalloc(int device, long G, long row0, long rows, const double *d
     }
     return CG_OK;
 }
+
+} // extern "C"
+namespace {
+int resolve_static_scratch(int device) { return static_scratch_ptr(device, nullptr); }
+}
+extern "C" {
 
 // ---------------------------------------------------------------- context ---
 
@@ -1429,6 +1464,7 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
                     "(equal blocks in rank order; the grid side must be divisible by the rank count, cf. cg.c:23-26)",
                     rank, nranks, (long)rank * (G / nranks), (long)(rank + 1) * (G / nranks), G);
     CGCHK(select_device(device));
+    (void)resolve_static_scratch(device);
 
     cg_ctx *c = new cg_ctx;
     c->device = device; c->n = n; c->G = G; c->row0 = row0; c->rows = rows; c->count = rows * G;

@@ -38,6 +38,13 @@ class DeviceVector:
         _l.check(_l.load().cg_copy_to_device(device, v.ptr, a.ctypes.data_as(C.c_void_p), a.size))
         return v
 
+    def copy_from_host(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if a.size != self.count:
+            raise ValueError(f"{a.size} values for a vector of {self.count}")
+        _l.check(_l.load().cg_copy_to_device(self.device, self.ptr, a.ctypes.data_as(C.c_void_p), a.size))
+        return self
+
     def to_host(self):
         out = np.empty(self.count, dtype=np.float64)
         _l.check(_l.load().cg_copy_to_host(self.device, out.ctypes.data_as(C.c_void_p), self.ptr, self.count))

@@ -124,9 +124,12 @@ int cg_xpay(int device, long count, double b, double *d, const double *g);
  * library runs on holds until the process ends, instead of library-allocated memory.  It allocates
  * nothing, creates no stream and does not synchronise: the work is enqueued on `stream` (a hipStream_t;
  * NULL = the null stream) and is complete when that stream reaches it.  dq_dev (DEVICE pointer, may be
- * NULL) receives d.q in the fast order, the value cg_stencil returns through dq_host.  Blocks that need
- * more than 65536 tiles (about 5e8 points) are rejected with CG_ERR_ARG.  All calls on one GPU share
- * the array: calls that overlap in time on the same GPU race on it.           */
+ * NULL) receives d.q in the fast order, the value cg_stencil returns through dq_host.  A block is cut into
+ * ceil(G / 512) column strips times row tiles of about 512 rows (never fewer than 16); blocks that need more
+ * than 65536 tiles -- some 1.7e10 points -- are rejected with CG_ERR_ARG.  All calls on one GPU share the array:
+ * calls that overlap in time on the same GPU race on it.  The array's address on a device is looked up by the
+ * first library call that touches the device (this one included); that first call must not be made under stream
+ * capture (CG_ERR_STATE), every later one may be.  The caller's current device is left as it was.             */
 int cg_stencil_noalloc(int device, long G, long row0, long rows, const double *d, const double *top,
                        const double *bot, double *q, double *dq_dev, void *stream);
 
