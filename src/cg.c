@@ -148,6 +148,15 @@ static void inspect(int device, int rank, int numprocs, int n, long row0, long r
     }
 }
 
+/* Every way out of main passes here: an MPI process that leaves without MPI_Finalize takes the job down noisily. */
+static int quit(int code)
+{
+#ifdef CG_USE_MPI
+    MPI_Finalize();
+#endif
+    return code;
+}
+
 int main(int argc, char **argv)
 {
     int rank = 0, numprocs = 1;
@@ -158,25 +167,27 @@ int main(int argc, char **argv)
 #endif
     if (argc < 2) {
         if (rank == 0) fprintf(stderr, "usage: %s <n> [iters] [rtol]\n", argv[0]);
-        return 1;
+        return quit(1);
     }
     const int n = atoi(argv[1]);
     const long iters = argc > 2 ? atol(argv[2]) : MAX_ITERS;
     const double rtol = argc > 3 ? atof(argv[3]) : 0.0;
     if (n < 2 || iters < 0 || rtol < 0) {
         if (rank == 0) printf("[ERROR] need n >= 2, iters >= 0, rtol >= 0.\n");
-        return 1;
+        return quit(1);
     }
     const long G = (long)n + 1;
-    if (G % numprocs != 0) {                                   /* cg.c:23-26, for row blocks */
-        if (rank == 0) printf("[ERROR] Number of points '%d+1' not divisible by number of processors '%d'.\n", n, numprocs);
-        return 1;
-    }
-    const long rows = G / numprocs, row0 = rank * rows, count = rows * G;
     const char *path = getenv("CG_PATH");
     const char *strict_e = getenv("CG_STRICT");
     const int strict = strict_e && *strict_e && *strict_e != '0';
     const int use_calls = path && strcmp(path, "calls") == 0;
+    const char *lay = getenv("CG_LAYOUT");
+    const int two_d = use_calls && lay && strcmp(lay, "2d") == 0 && numprocs > 1;   /* the reference's own decomposition */
+    if (!two_d && G % numprocs != 0) {                         /* cg.c:23-26, for row blocks */
+        if (rank == 0) printf("[ERROR] Number of points '%d+1' not divisible by number of processors '%d'.\n", n, numprocs);
+        return quit(1);
+    }
+    const long rows = G / numprocs, row0 = rank * rows, count = rows * G;   /* (row blocks) */
 
     int my_stencil[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};              /* cg.c:33 */
     const char *ste = getenv("CG_STENCIL");
@@ -189,7 +200,7 @@ int main(int argc, char **argv)
             my_stencil[1] = v[0]; my_stencil[3] = v[1]; my_stencil[4] = v[2]; my_stencil[5] = v[3]; my_stencil[7] = v[4];
         } else {
             if (rank == 0) printf("[ERROR] CG_STENCIL needs five integers (up,left,centre,right,down) or all nine.\n");
-            return 1;
+            return quit(1);
         }
     }
 
@@ -201,19 +212,17 @@ int main(int argc, char **argv)
     if (use_calls) {
         /* ---- the reference's loop, one call per step (cg.c:30-130) ---- */
         bytes_per_point = 112;                                         /* six separate passes, as in the reference */
-        const char *lay = getenv("CG_LAYOUT");
-        const int two_d = lay && strcmp(lay, "2d") == 0 && numprocs > 1;
         int chunk = (int)G;                                            /* row blocks: chunklength is the row length */
         if (two_d) {
             const int side = (int)(sqrt((double)numprocs) + 0.5);
-            if (side * side != numprocs) { if (rank == 0) printf("[ERROR] Number of processors must be a perfect square.\n"); return 1; }   /* cg.c:15-18 */
-            if (G % side != 0) { if (rank == 0) printf("[ERROR] Number of points '%d+1' not divisible by the %d x %d processor grid.\n", n, side, side); return 1; }
+            if (side * side != numprocs) { if (rank == 0) printf("[ERROR] Number of processors must be a perfect square.\n"); return quit(1); }   /* cg.c:15-18 */
+            /* cg.c:21-26 tests (n+1)^2 % numprocs, which for a square rank count is this */
+            if (G % side != 0) { if (rank == 0) printf("[ERROR] Number of points '%d+1' not divisible by the %d x %d processor grid.\n", n, side, side); return quit(1); }
             chunk = (int)(G / side);                                   /* cg.c:21-22 */
         }
         MPI_Settings *settings = init_mpi_settings(numprocs, chunk);
         device = settings->device;
         settings->strict_dot = strict;
-        const long count_l = settings->local_rows * settings->local_cols;
         stencil_struct *stencil = (stencil_struct *)malloc(sizeof(stencil_struct));
         stencil->size = 3;
         stencil->extent = stencil->size / 2;
@@ -221,6 +230,7 @@ int main(int argc, char **argv)
         memcpy(stencil->stencil, my_stencil, sizeof(my_stencil));
 
         d_struct *ld = init_locald(n, chunk, rank, settings);          /* cg.c:41 */
+        const long count_l = settings->local_rows * settings->local_cols;   /* (the decomposition is settled by now) */
         double *locald = ld->locald;
         double *localg = init_localg(chunk, locald);                   /* cg.c:43 */
         double *localu = NULL, *localq = NULL;
@@ -259,7 +269,7 @@ int main(int argc, char **argv)
         /* ---- whole loop on the device ---- */
         int ndev = 0;
         CK(cg_device_count(&ndev), "cg_device_count");
-        if (ndev < 1) { if (rank == 0) printf("[ERROR] no GPU visible; this build has no CPU path.\n"); return 1; }
+        if (ndev < 1) { if (rank == 0) printf("[ERROR] no GPU visible; this build has no CPU path.\n"); return quit(1); }
         device = rank % ndev;
         cg_ctx *ctx = NULL;
         CK(cg_create(&ctx, device, n, row0, rows, rank, numprocs), "cg_create");
@@ -275,7 +285,7 @@ int main(int argc, char **argv)
         const char *snp = getenv("CG_STRICT_NP");
         if (strict && snp && *snp) {
             const int p = atoi(snp), side = (int)(sqrt((double)p) + 0.5);
-            if (side * side != p) { if (rank == 0) printf("[ERROR] Number of processors must be a perfect square.\n"); return 1; }   /* cg.c:15-18 */
+            if (side * side != p) { if (rank == 0) printf("[ERROR] Number of processors must be a perfect square.\n"); return quit(1); }   /* cg.c:15-18 */
             CK(cg_set_option(ctx, CG_OPT_STRICT_BLOCKS, side), "cg_set_option(strict blocks)");
         }
 #ifdef CG_USE_MPI

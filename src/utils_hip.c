@@ -57,29 +57,11 @@ static void check_stencil(const stencil_struct *s)
     }
 }
 
-/* utils.c:383-420.  chunklength = row length n+1; this rank owns (n+1)/numprocs rows. */
-MPI_Settings *init_mpi_settings(int numprocs, int chunklength)
+/* The rank's place in the decomposition: row blocks (chunklength = the row length n+1, this rank owns
+ * (n+1)/numprocs rows), or the reference's side x side chunks (utils.c:408-417, chunklength = (n+1)/side). */
+static void set_layout(MPI_Settings *s, int two_d, int chunklength)
 {
-    MPI_Settings *s = (MPI_Settings *)calloc(1, sizeof(MPI_Settings));
-    if (!s) { fprintf(stderr, "[ERROR] out of host memory\n"); exit(1); }
-    int rank = 0;
-#ifdef CG_USE_MPI
-    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
-    s->cartcomm = MPI_COMM_WORLD;
-#else
-    if (numprocs != 1) {
-        fprintf(stderr, "[ERROR] this build has no MPI: numprocs must be 1 (got %d)\n", numprocs);
-        exit(1);
-    }
-#endif
-    const char *lay = getenv("CG_LAYOUT");
-    const int two_d = lay && strcmp(lay, "2d") == 0 && numprocs > 1;
-    int ndev = 0;
-    CK(cg_device_count(&ndev), "cg_device_count");
-    if (ndev < 1) { fprintf(stderr, "[ERROR] no GPU visible; this build has no CPU path\n"); exit(1); }
-    s->rank = rank;
-    s->numprocs = numprocs;
-    s->device = rank % ndev;
+    const int rank = s->rank, numprocs = s->numprocs;
     s->layout2d = two_d;
     if (two_d) {
         /* utils.c:408-417: a side x side non-periodic cartesian grid, rank = carti*side + cartj */
@@ -114,6 +96,37 @@ MPI_Settings *init_mpi_settings(int numprocs, int chunklength)
         s->bottomrank = rank < numprocs - 1 ? rank + 1 : -1;
         s->leftrank = s->rightrank = -1;
     }
+}
+
+/* utils.c:383-420. */
+MPI_Settings *init_mpi_settings(int numprocs, int chunklength)
+{
+    MPI_Settings *s = (MPI_Settings *)calloc(1, sizeof(MPI_Settings));
+    if (!s) { fprintf(stderr, "[ERROR] out of host memory\n"); exit(1); }
+    int rank = 0;
+#ifdef CG_USE_MPI
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+    s->cartcomm = MPI_COMM_WORLD;
+#else
+    if (numprocs != 1) {
+        fprintf(stderr, "[ERROR] this build has no MPI: numprocs must be 1 (got %d)\n", numprocs);
+        exit(1);
+    }
+#endif
+    int ndev = 0;
+    CK(cg_device_count(&ndev), "cg_device_count");
+    if (ndev < 1) { fprintf(stderr, "[ERROR] no GPU visible; this build has no CPU path\n"); exit(1); }
+    s->rank = rank;
+    s->numprocs = numprocs;
+    s->device = rank % ndev;
+    /* Which decomposition `chunklength` belongs to: CG_LAYOUT says it (2d / rows); unset, a single rank has only one,
+     * and several ranks are decided in init_locald, the first call that also knows n: the reference's own main passes
+     * (n+1)/sqrt(P) (cg.c:22), the row-block driver passes n+1. */
+    const char *lay = getenv("CG_LAYOUT");
+    if (numprocs == 1) set_layout(s, 0, chunklength);
+    else if (lay && strcmp(lay, "2d") == 0) set_layout(s, 1, chunklength);
+    else if (lay && *lay) set_layout(s, 0, chunklength);
+    else s->layout2d = -1;
     s->itags = (int *)malloc((size_t)numprocs * sizeof(int));
     s->jtags = (int *)malloc((size_t)numprocs * sizeof(int));
     s->irequests = (MPI_Request *)calloc((size_t)numprocs, sizeof(MPI_Request));
@@ -131,6 +144,13 @@ MPI_Settings *init_mpi_settings(int numprocs, int chunklength)
 d_struct *init_locald(const int n, const int chunklength, const int myrank, MPI_Settings *s)
 {
     (void)myrank;
+    if (s->layout2d < 0) {                       /* undecided so far: n tells which decomposition chunklength belongs to */
+        int side = 1;
+        while ((side + 1) * (side + 1) <= s->numprocs) ++side;
+        const int square = side * side == s->numprocs;
+        if (chunklength != n + 1 && square && (long)chunklength * side == (long)n + 1) set_layout(s, 1, chunklength);
+        else set_layout(s, 0, chunklength);
+    }
     if (!s->layout2d && chunklength != n + 1) {
         fprintf(stderr, "[ERROR] row-block build: chunklength must be the row length n+1 = %d (got %d); "
                         "CG_LAYOUT=2d selects the reference's sqrt(P) x sqrt(P) chunks\n", n + 1, chunklength);

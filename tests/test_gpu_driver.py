@@ -179,3 +179,32 @@ def test_two_dimensional_layout_other_coefficients_and_fast_order(golden):
     _, m = run(["255"], env={"CG_PATH": "calls", "CG_LAYOUT": "2d"}, mpi=4)
     q1_ref = float.fromhex(rec["q1_hex"])
     assert abs(float(m.group(1)) - q1_ref) <= 5e-8 * q1_ref
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+@pytest.mark.parametrize("n,iters,np_", [(5, 4, 4), (8, 6, 9), (14, 9, 9)])
+def test_two_dimensional_layout_accepts_what_the_reference_accepts(oracle, n, iters, np_):
+    # cg.c:21-26 wants (n+1)^2 divisible by the rank count: 6 x 6 points on 4 ranks, 9 x 9 and 15 x 15 on 9 -- grids
+    # whose side is NOT divisible by the rank count, which the row-block rule would refuse.  Expected bits on 4 ranks:
+    # the restatement in the reference's multi-rank summation layout (pinned against `mpirun -np 4 / 16` of the
+    # reference).  Nine ranks: MPICH combines a rank count that is no power of two in another order, which the
+    # restatement does not cover -- parity unpinned there, the result is held against the single-rank one at 1e-12.
+    side = int(round(np_ ** 0.5))
+    _, m = run([str(n), str(iters)], env={"CG_PATH": "calls", "CG_LAYOUT": "2d", "CG_STRICT": "1"}, mpi=np_)
+    assert int(m.group(5)) == np_
+    if np_ == 4:
+        assert m.group(2) == float(oracle.cg(n, iters, blocks2d=side)["q1"]).hex()
+    else:
+        q1 = oracle.cg(n, iters)["q1"]
+        assert abs(float(m.group(1)) - q1) <= 1e-12 * q1
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+def test_bad_rank_counts_end_with_the_references_message_and_a_clean_exit():
+    # every way out passes MPI_Finalize: mpirun reports the plain exit code, no abort noise
+    p = subprocess.run([MPIRUN, "-np", "2", CG_MPI, "4"], capture_output=True, text=True, timeout=120)       # 5 rows on 2 ranks
+    assert p.returncode != 0 and "not divisible" in p.stdout
+    assert "abort" not in (p.stdout + p.stderr).lower() and "BAD TERMINATION" not in p.stderr
+    p = subprocess.run([MPIRUN, "-np", "2", CG_MPI, "7"], env=dict(os.environ, CG_PATH="calls", CG_LAYOUT="2d"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "perfect square" in p.stdout
