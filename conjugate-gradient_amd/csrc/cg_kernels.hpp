@@ -1207,11 +1207,16 @@ __global__ __launch_bounds__(kBlock) void k_init_d_block(double *d, long G, long
 // with the pads received from above / below (utils.c:74-104), first / last column with the pads from the left
 // / right (utils.c:121-151) and the four corner points with two pads each (utils.c:156-218).  A null pad means
 // the chunk touches the global boundary on that side, where q is not written (the reference's loops skip those
-// points the same way).  Five-point sum in the reference's order: up, left, centre, right, down.
+// points the same way).  Five-point sum in the reference's order: up, left, centre, right, down.  With corner
+// coefficients (nine-point sum, in array order) the chunk's four corner points also need the values diagonally
+// across: corner[0..3] = the points up-left, up-right, down-left, down-right of the chunk (what the reference's
+// d_struct reserves corner_pad for, utils.h:15, and never fills); an entry is read only where both adjacent
+// pads exist, i.e. where there is a diagonal neighbour.
 struct BlockArgs {
     const double *d;                  // rows x cols, row-major
     const double *top, *bot;          // cols doubles each, or nullptr
     const double *left, *right;       // rows doubles each, or nullptr
+    const double *corner;             // four doubles, or nullptr (five-point stencils, chunks without diagonal neighbours)
     double *q;
     long rows, cols;
     Coef9 coef;
@@ -1230,7 +1235,16 @@ __global__ __launch_bounds__(kBlock) void k_stencil_block(const BlockArgs a)
         const double down = (r < a.rows - 1) ? a.d[k + a.cols] : a.bot[c];
         const double lf = (c > 0) ? a.d[k - 1] : a.left[r];
         const double rt = (c < a.cols - 1) ? a.d[k + 1] : a.right[r];
-        a.q[k] = five_point(a.coef, up, lf, a.d[k], rt, down);
+        if (!a.coef.nine) {
+            a.q[k] = five_point(a.coef, up, lf, a.d[k], rt, down);
+            continue;
+        }
+        const bool r_lo = r > 0, r_hi = r < a.rows - 1, c_lo = c > 0, c_hi = c < a.cols - 1;
+        const double ul = r_lo ? (c_lo ? a.d[k - a.cols - 1] : a.left[r - 1]) : (c_lo ? a.top[c - 1] : a.corner[0]);
+        const double ur = r_lo ? (c_hi ? a.d[k - a.cols + 1] : a.right[r - 1]) : (c_hi ? a.top[c + 1] : a.corner[1]);
+        const double dl = r_hi ? (c_lo ? a.d[k + a.cols - 1] : a.left[r + 1]) : (c_lo ? a.bot[c - 1] : a.corner[2]);
+        const double dr = r_hi ? (c_hi ? a.d[k + a.cols + 1] : a.right[r + 1]) : (c_hi ? a.bot[c + 1] : a.corner[3]);
+        a.q[k] = nine_point(a.coef, ul, up, ur, lf, a.d[k], rt, dl, down, dr);
     }
 }
 

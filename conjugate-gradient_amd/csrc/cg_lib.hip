@@ -1194,14 +1194,22 @@ int cg_init_d_block(int device, long n, long row0, long col0, long rows, long co
 int cg_stencil_block(int device, const int *stencil9, long rows, long cols, const double *d, const double *top,
                      const double *bot, const double *left, const double *right, double *q)
 {
+    return cg_stencil_block9(device, stencil9, rows, cols, d, top, bot, left, right, nullptr, q);
+}
+
+int cg_stencil_block9(int device, const int *stencil9, long rows, long cols, const double *d, const double *top,
+                      const double *bot, const double *left, const double *right, const double *corners, double *q)
+{
     if (!stencil9 || !d || !q || rows < 1 || cols < 1) return fail(CG_ERR_ARG, "cg_stencil_block: bad arguments");
-    if (stencil9[0] != 0 || stencil9[2] != 0 || stencil9[6] != 0 || stencil9[8] != 0)
-        return fail(CG_ERR_ARG, "cg_stencil_block: a chunk with column pads has no corner values (the reference's corner_pad, "
-                    "utils.h:15, is never filled): corner coefficients need the row-block layout");
+    const bool nine = stencil9[0] != 0 || stencil9[2] != 0 || stencil9[6] != 0 || stencil9[8] != 0;
+    const bool diagonal = (top && left) || (top && right) || (bot && left) || (bot && right);
+    if (nine && diagonal && !corners)
+        return fail(CG_ERR_ARG, "cg_stencil_block: corner coefficients on a chunk with diagonal neighbours need the four corner "
+                    "values (cg_stencil_block9; the reference's corner_pad, utils.h:15)");
     DeviceScratch *sc;
     CGCHK(get_scratch(device, &sc));
     cg::BlockArgs a;
-    a.d = d; a.top = top; a.bot = bot; a.left = left; a.right = right; a.q = q; a.rows = rows; a.cols = cols;
+    a.d = d; a.top = top; a.bot = bot; a.left = left; a.right = right; a.corner = corners; a.q = q; a.rows = rows; a.cols = cols;
     a.coef = coef_from9(stencil9);
     hipLaunchKernelGGL(cg::k_stencil_block, dim3(flat_blocks(rows * cols, 0)), dim3(kBlock), 0, sc->stream, a);
     HIPCHK(hipGetLastError());

@@ -66,6 +66,8 @@ SIGNATURES = {
     "cg_init_d_block": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p]),
     "cg_stencil_block": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_stencil_block9": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_pack_column": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p]),
     "cg_verify_u": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_double, _dp, _dp]),
     "cg_stencil_noalloc": (C.c_int, [C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,

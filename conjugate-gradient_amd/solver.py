@@ -108,9 +108,14 @@ def init_d_block(n, row0, col0, rows, cols, d, device=0):
     _l.check(_l.load().cg_init_d_block(device, n, row0, col0, rows, cols, _p(d)))
 
 
-def stencil_block(rows, cols, d, q, top=None, bot=None, left=None, right=None, device=0, coef5=(-1, -1, 4, -1, -1)):
-    """q = A d on a rows x cols chunk with its four pads (None = global boundary): apply_stencil_parallel, utils.c:38-219."""
-    _l.check(_l.load().cg_stencil_block(device, _stencil9(coef5), rows, cols, _p(d), _p(top), _p(bot), _p(left), _p(right), _p(q)))
+def stencil_block(rows, cols, d, q, top=None, bot=None, left=None, right=None, device=0, coef5=(-1, -1, 4, -1, -1), corners=None):
+    """q = A d on a rows x cols chunk with its four pads (None = global boundary): apply_stencil_parallel, utils.c:38-219.
+    corners: device vector of the four values diagonally across the chunk's corners (nine-point coefficients only)."""
+    if corners is None:
+        _l.check(_l.load().cg_stencil_block(device, _stencil9(coef5), rows, cols, _p(d), _p(top), _p(bot), _p(left), _p(right), _p(q)))
+    else:
+        _l.check(_l.load().cg_stencil_block9(device, _stencil9(coef5), rows, cols, _p(d), _p(top), _p(bot), _p(left), _p(right),
+                                             _p(corners), _p(q)))
 
 
 def pack_column(rows, cols, src, col, dst, device=0):

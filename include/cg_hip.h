@@ -95,9 +95,16 @@ int cg_init_d_block(int device, long n, long row0, long col0, long rows, long co
 /* q = A d on the chunk: apply_stencil_parallel's interior (utils.c:50), edge rows (:74-104), edge columns
  * (:121-151) and corner points (:156-218).  top / bot: the `cols` values just above / below the chunk, left /
  * right: the `rows` values beside it (device pointers); NULL = the chunk touches the global boundary there and q
- * is not written on that edge.  Corner coefficients must be zero here (the reference never fills corner_pad). */
+ * is not written on that edge.  Corner coefficients need cg_stencil_block9 where the chunk has a diagonal neighbour. */
 int cg_stencil_block(int device, const int *stencil9, long rows, long cols, const double *d, const double *top,
                      const double *bot, const double *left, const double *right, double *q);
+/* The same with all nine coefficients: corners[0..3] (device pointer) = the values diagonally across the chunk's
+ * corners -- up-left, up-right, down-left, down-right -- which the nine-point sum needs at the chunk's four corner
+ * points.  This is what d_struct::corner_pad (utils.h:15) is laid out for; the reference never fills or reads it
+ * (utils.c:156-218 handles the corner points with two pads each, five coefficients).  An entry is read only where
+ * both adjacent pads exist; corners may be NULL for five-point stencils and for chunks without diagonal neighbours. */
+int cg_stencil_block9(int device, const int *stencil9, long rows, long cols, const double *d, const double *top,
+                      const double *bot, const double *left, const double *right, const double *corners, double *q);
 /* dst[r] = src[r*cols + col], r = 0..rows-1: the sending side of the reference's strided column datatype
  * (MPI_Type_vector, utils.c:392; used at utils.c:261,270).                                                   */
 int cg_pack_column(int device, long rows, long cols, const double *src, long col, double *dst);

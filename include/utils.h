@@ -51,7 +51,8 @@ extern "C" {
 typedef struct my_stencil {    /* utils.h:3-7 */
     int size;
     int extent;
-    int* stencil;              /* host array of size*size ints; only the 5-point cross {0,-1,0,-1,4,-1,0,-1,0} is supported */
+    int* stencil;              /* host array of size*size ints (size = 3), row-wise; all nine entries are honoured (the reference
+                                  reads entries 1, 3, 4, 5, 7 only, utils.c:27-31) */
 } stencil_struct;
 
 typedef struct my_d {          /* utils.h:9-16; all DEVICE pointers */
@@ -60,7 +61,9 @@ typedef struct my_d {          /* utils.h:9-16; all DEVICE pointers */
     double* locald;
     double* bottom_pad;        /* row below the block, NULL at the global boundary */
     double* right_pad;         /* column right of the chunk, NULL at the global boundary and in row blocks */
-    double* corner_pad;        /* unused, as in the reference */
+    double* corner_pad;        /* two-dimensional layout: the four values diagonally across the chunk's corners (up-left,
+                                  up-right, down-left, down-right), filled by exchange_boundaries for nine-point coefficients;
+                                  declared and never used in the reference (utils.h:15) */
 } d_struct;
 
 typedef struct my_MPI_Settings {   /* utils.h:18-32 */

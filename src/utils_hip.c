@@ -132,8 +132,8 @@ MPI_Settings *init_mpi_settings(int numprocs, int chunklength)
     s->irequests = (MPI_Request *)calloc((size_t)numprocs, sizeof(MPI_Request));
     s->jrequests = (MPI_Request *)calloc((size_t)numprocs, sizeof(MPI_Request));
     for (int i = 0; i < numprocs; ++i) s->itags[i] = s->jtags[i] = i;      /* utils.c:401-404 */
-    s->host_row[0] = (double *)malloc((size_t)chunklength * sizeof(double));
-    s->host_row[1] = (double *)malloc((size_t)chunklength * sizeof(double));
+    s->host_row[0] = (double *)malloc(((size_t)chunklength + 2) * sizeof(double));     /* a row, and a corner value at each end */
+    s->host_row[1] = (double *)malloc(((size_t)chunklength + 2) * sizeof(double));
     const char *e = getenv("CG_STRICT");
     s->strict_dot = (e && *e && *e != '0') ? 1 : 0;
     g_settings = s;
@@ -168,6 +168,8 @@ d_struct *init_locald(const int n, const int chunklength, const int myrank, MPI_
     if (s->bottomrank >= 0) CK(cg_malloc(s->device, cols, &d->bottom_pad), "cg_malloc(bottom_pad)"); /* utils.c:290-293 */
     if (s->leftrank >= 0) CK(cg_malloc(s->device, rows, &d->left_pad), "cg_malloc(left_pad)");       /* utils.c:310-316 */
     if (s->rightrank >= 0) CK(cg_malloc(s->device, rows, &d->right_pad), "cg_malloc(right_pad)");    /* utils.c:306-309 */
+    /* the four values diagonally across the chunk's corners (nine-point coefficients; zero until the first exchange) */
+    if (s->layout2d) CK(cg_malloc(s->device, 4, &d->corner_pad), "cg_malloc(corner_pad)");
     if (s->layout2d) CK(cg_init_d_block(s->device, n, s->row0, s->col0, rows, cols, d->locald), "cg_init_d_block");
     else CK(cg_init_d(s->device, n, s->row0, rows, d->locald), "cg_init_d");
     return d;
@@ -203,11 +205,50 @@ static void swap_with(MPI_Settings *s, int peer, const double *dev_send, double 
 }
 #endif
 
+#ifdef CG_USE_MPI
+/* Two-dimensional layout, rows with the corner values riding along: the row going up or down is sent with the first
+ * (last) element of this rank's left and right pads at its ends -- the points that lie diagonally across the
+ * receiver's corners -- and received as [corner, row, corner].  The columns must have been exchanged before.
+ * first = 1: the chunk's first row goes to `peer` above, its reply fills top_pad and corners 0, 1; first = 0: the
+ * last row goes down, the reply fills bottom_pad and corners 2, 3. */
+static void swap_row_with_corners(MPI_Settings *s, d_struct *ld, int peer, int first)
+{
+    const long cols = s->local_cols, rows = s->local_rows;
+    const long r = first ? 0 : rows - 1;
+    MPI_Status st;
+    double *out = s->host_row[0], *in = s->host_row[1];
+    out[0] = out[cols + 1] = 0.0;
+    if (ld->left_pad) CK(cg_copy_to_host(s->device, &out[0], ld->left_pad + r, 1), "corner d2h");
+    CK(cg_copy_to_host(s->device, out + 1, ld->locald + r * cols, cols), "halo d2h");
+    if (ld->right_pad) CK(cg_copy_to_host(s->device, &out[cols + 1], ld->right_pad + r, 1), "corner d2h");
+    MPI_Sendrecv(out, (int)cols + 2, MPI_DOUBLE, peer, s->itags[s->rank], in, (int)cols + 2, MPI_DOUBLE, peer, s->itags[peer],
+                 s->cartcomm, &st);
+    CK(cg_copy_to_device(s->device, first ? ld->top_pad : ld->bottom_pad, in + 1, cols), "halo h2d");
+    const double pair[2] = {in[0], in[cols + 1]};
+    CK(cg_copy_to_device(s->device, ld->corner_pad + (first ? 0 : 2), pair, 2), "corner h2d");
+}
+#endif
+
 void exchange_boundaries(const int chunklength, d_struct *ld, const int myrank, MPI_Settings *s)
 {
     (void)myrank; (void)chunklength;
 #ifdef CG_USE_MPI
     const long cols = s->local_cols, rows = s->local_rows;
+    if (s->layout2d) {
+        /* columns first (utils.c:255-272), then the rows with the corner values at their ends: what the
+         * reference's corner_pad (utils.h:15) would hold if its nine-point case had been finished */
+        if (ld->right_pad != NULL) {
+            CK(cg_pack_column(s->device, rows, cols, ld->locald, cols - 1, s->dev_col[0]), "cg_pack_column");
+            swap_with(s, s->rightrank, s->dev_col[0], ld->right_pad, rows);
+        }
+        if (ld->left_pad != NULL) {
+            CK(cg_pack_column(s->device, rows, cols, ld->locald, 0, s->dev_col[1]), "cg_pack_column");
+            swap_with(s, s->leftrank, s->dev_col[1], ld->left_pad, rows);
+        }
+        if (ld->bottom_pad != NULL) swap_row_with_corners(s, ld, s->bottomrank, 0);
+        if (ld->top_pad != NULL) swap_row_with_corners(s, ld, s->toprank, 1);
+        return;
+    }
     /* last row down, the lower neighbour's first row back (utils.c:234-239); first row up (utils.c:243-248) */
     if (ld->bottom_pad != NULL) swap_with(s, s->bottomrank, ld->locald + (rows - 1) * cols, ld->bottom_pad, cols);
     if (ld->top_pad != NULL) swap_with(s, s->toprank, ld->locald, ld->top_pad, cols);
@@ -233,8 +274,8 @@ void apply_stencil_parallel(const int chunklength, stencil_struct *my_stencil, d
     check_stencil(my_stencil);
     exchange_boundaries(chunklength, ld, myrank, s);
     if (s->layout2d)
-        CK(cg_stencil_block(s->device, my_stencil->stencil, s->local_rows, s->local_cols, ld->locald, ld->top_pad, ld->bottom_pad,
-                            ld->left_pad, ld->right_pad, localq), "cg_stencil_block");
+        CK(cg_stencil_block9(s->device, my_stencil->stencil, s->local_rows, s->local_cols, ld->locald, ld->top_pad, ld->bottom_pad,
+                             ld->left_pad, ld->right_pad, ld->corner_pad, localq), "cg_stencil_block9");
     else
         CK(cg_stencil9(s->device, my_stencil->stencil, chunklength, s->row0, s->local_rows, ld->locald, ld->top_pad, ld->bottom_pad,
                        localq, NULL), "cg_stencil");
@@ -303,6 +344,7 @@ void free_struct_elems(stencil_struct *stencil, d_struct *ld, MPI_Settings *s)
     if (ld->locald) cg_free(dev, ld->locald);
     if (ld->bottom_pad) cg_free(dev, ld->bottom_pad);
     if (ld->right_pad) cg_free(dev, ld->right_pad);
+    if (ld->corner_pad) cg_free(dev, ld->corner_pad);
     if (s->dev_col[0]) cg_free(dev, s->dev_col[0]);
     if (s->dev_col[1]) cg_free(dev, s->dev_col[1]);
     free(s->itags); free(s->jtags); free(s->irequests); free(s->jrequests);

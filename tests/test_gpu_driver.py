@@ -193,7 +193,7 @@ def test_two_dimensional_layout_accepts_what_the_reference_accepts(oracle, n, it
     _, m = run([str(n), str(iters)], env={"CG_PATH": "calls", "CG_LAYOUT": "2d", "CG_STRICT": "1"}, mpi=np_)
     assert int(m.group(5)) == np_
     if np_ == 4:
-        assert m.group(2) == float(oracle.cg(n, iters, blocks2d=side)["q1"]).hex()
+        assert float.fromhex(m.group(2)) == float(oracle.cg(n, iters, blocks2d=side)["q1"])
     else:
         q1 = oracle.cg(n, iters)["q1"]
         assert abs(float(m.group(1)) - q1) <= 1e-12 * q1
@@ -208,3 +208,22 @@ def test_bad_rank_counts_end_with_the_references_message_and_a_clean_exit():
     p = subprocess.run([MPIRUN, "-np", "2", CG_MPI, "7"], env=dict(os.environ, CG_PATH="calls", CG_LAYOUT="2d"),
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "perfect square" in p.stdout
+
+
+@pytest.mark.skipif(not (os.path.exists(CG_MPI) and os.path.exists(MPIRUN)), reason="MPI driver not built")
+@pytest.mark.parametrize("n,iters,np_", [(63, 30, 4), (63, 30, 16), (255, 61, 16)])
+def test_nine_point_stencil_in_the_two_dimensional_layout(oracle, n, iters, np_):
+    # all nine coefficients on 2 x 2 and 4 x 4 chunks: row and column halos plus the four corner values exchanged with the
+    # diagonal neighbours (corner_pad, utils.h:15).  Expected bits: the single-block CPU restatement with the dot products
+    # in the reference's multi-rank summation layout.  The corner terms have no counterpart in the reference's own code,
+    # so against the reference this parity is unpinned; the five-point part of the same path is pinned by the goldens above.
+    coef = (-1, -1, -1, -1, 8, -1, -1, -1, -1)
+    side = int(round(np_ ** 0.5))
+    oracle.set_stencil(coef)
+    try:
+        ref = oracle.cg(n, iters, blocks2d=side)
+    finally:
+        oracle.set_stencil()
+    _, m = run([str(n), str(iters)], env={"CG_PATH": "calls", "CG_LAYOUT": "2d", "CG_STRICT": "1",
+                                          "CG_STENCIL": ",".join(str(c) for c in coef)}, mpi=np_)
+    assert float.fromhex(m.group(2)) == float(ref["q1"]) and int(m.group(5)) == np_      # (the same double: %a and hex() pad differently)

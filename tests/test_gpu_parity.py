@@ -573,6 +573,41 @@ def test_chunk_operators_of_the_two_dimensional_layout_bitwise(cg, oracle, rng, 
             assert np.array_equal(bits(d0.to_host().reshape(c, c)), bits(want_d0[r0:r0 + c, c0:c0 + c])), (ci, cj)
 
 
+@pytest.mark.parametrize("G,side", [(64, 2), (60, 3), (256, 4), (8, 4)])
+def test_chunk_stencil_with_corner_coefficients_bitwise(cg, oracle, rng, G, side):
+    # all nine coefficients on the chunks of a side x side decomposition: the four pads and the four values diagonally
+    # across the corners (the reference's never-filled corner_pad, utils.h:15).  The corner terms have no counterpart in
+    # the reference's code -- parity unpinned for them; the expected bits are the single-block CPU restatement's.
+    c = G // side
+    full = rng.standard_normal((G, G))
+    oracle.set_stencil(NINE)
+    try:
+        want_q = oracle.stencil(full)
+    finally:
+        oracle.set_stencil()
+    at = lambda i, j: full[i, j] if 0 <= i < G and 0 <= j < G else 0.0
+    for ci in range(side):
+        for cj in range(side):
+            r0, c0 = ci * c, cj * c
+            d = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0:r0 + c, c0:c0 + c]))
+            pads = {}
+            pads["top"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0 - 1, c0:c0 + c])) if ci > 0 else None
+            pads["bot"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0 + c, c0:c0 + c])) if ci < side - 1 else None
+            pads["left"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0:r0 + c, c0 - 1])) if cj > 0 else None
+            pads["right"] = cg.DeviceVector.from_host(np.ascontiguousarray(full[r0:r0 + c, c0 + c])) if cj < side - 1 else None
+            corners = cg.DeviceVector.from_host(np.array([at(r0 - 1, c0 - 1), at(r0 - 1, c0 + c), at(r0 + c, c0 - 1), at(r0 + c, c0 + c)]))
+            q = cg.DeviceVector(c * c)
+            cg.stencil_block(c, c, d, q, coef5=NINE, corners=corners, **pads)
+            assert np.array_equal(bits(q.to_host().reshape(c, c)), bits(want_q[r0:r0 + c, c0:c0 + c])), (ci, cj)
+    # without the corner values a chunk that has a diagonal neighbour is refused, one that has none is not
+    d = cg.DeviceVector.from_host(np.ascontiguousarray(full[:c, :c]))
+    q = cg.DeviceVector(c * c)
+    pad = cg.DeviceVector(c)
+    with pytest.raises(cg.CGError):
+        cg.stencil_block(c, c, d, q, coef5=NINE, bot=pad, right=pad)
+    cg.stencil_block(c, c, d, q, coef5=NINE, bot=pad)
+
+
 # -------------------------------------------------------- solution checks on the device -----
 
 @pytest.mark.parametrize("n,iters", [(15, 10), (255, 200), (1023, 200)])
