@@ -264,7 +264,9 @@ struct cg_ctx {
     int pf_update_u = 0;                  // pass 2 with the u update: what choose_placement measured (0 = default)
     long tile_wgs = 0;
     bool graph_explicit = false;          // the caller set CG_OPT_GRAPH_ITERS
-    int overlap = 1;                      // multi-rank lean schedule: halo exchange beside the interior rows
+    int overlap = 0;                      // multi-rank lean schedule: 1 = halo exchange beside the interior rows.  Off by default:
+                                          // the one measurement there is (a single-rank communicator, the wire being the GPU's own
+                                          // memory) has the fork and join cost more than they hide; bench.py times both and keeps the faster
     int rehearse = 0;                     // single rank with an RCCL communicator: issue the multi-rank traffic anyway
     int resum_q0 = 0;                     // a solve that continues the previous one sums q0 = g.g again (cg.c:55) instead of taking it over
 

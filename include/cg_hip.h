@@ -188,8 +188,9 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_STRICT_AUDIT 18 /* self-test of CG_OPT_STRICT_SPEC (slow): 1 = after every dot product each chunk summary is
                                   checked against one recomputed from the products, and the plan-driven walk against the
                                   plain hierarchical one; cg_get_option returns the failures counted so far (must be 0) */
-#define CG_OPT_OVERLAP     13  /* several ranks, lean schedule: 1 (default) = the new gradient's boundary rows travel on a
-                                  second stream while the rows between them are computed; 0 = exchange in line */
+#define CG_OPT_OVERLAP     13  /* several ranks, lean schedule: 1 = the new gradient's boundary rows travel on a second stream
+                                  while the rows between them are computed; 0 (default) = exchange in line.  Which is faster
+                                  depends on the link; time both (bench.py does) */
 #define CG_OPT_RESUM_Q0    19  /* 1 = a cg_solve that continues the previous one (see cg_solve) still begins with the dot
                                   product q0 = g.g of cg.c:55 instead of taking q1 over: the reference's timed region
                                   (cg.c:50-55) with warm vectors.  Strict order: the same bits either way.  Default 0 */

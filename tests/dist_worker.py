@@ -71,6 +71,7 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast", digest=False):
         s.configure(reduce=cg.REDUCE_STRICT, schedule=s.schedule,
                     strict_impl={"strict": cg.STRICT_AUTO, "strict_replay": cg.STRICT_REPLAY,
                                  "strict_parallel": cg.STRICT_PARALLEL}[order])
+    s.configure(overlap=os.environ.get("CG_TEST_OVERLAP", "1") != "0")   # the split second pass (edge strips first) unless told otherwise
     s.comm_init_host(tr)
     s.comm_selftest()                             # tagged all-gather and row exchange arrive where they should
     s.init_problem()

@@ -48,3 +48,8 @@ def test_bench_two_ranks_sharing_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 1024 and d["config"]["transport"] == "host"
     assert d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
+    # overlap of the halo exchange: measured both ways before the timed region, the faster one in effect
+    om = d["config"]["overlap_ms"]
+    assert set(om) == {"0", "1"} and all(v > 0 for v in om.values())
+    assert d["config"]["overlap"] == int(min(om, key=om.get))
+    assert d["config"]["reduce"] == "strict" and d["other_order"]["reduce"] == "fast"
