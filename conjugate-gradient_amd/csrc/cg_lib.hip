@@ -1423,6 +1423,9 @@ static int choose_placement(cg_ctx *c)
         *ms = 2.0 * t[0] + t[1] + 0.5 * (t[2] + t[3]);   // both forms count: the strict order keeps one row in flight there
         return CG_OK;
     };
+    // diagnostic: CG_PLACEMENT_KEEP=worst keeps the slowest set instead (to put a slow placement under the profiler)
+    const char *keep = getenv("CG_PLACEMENT_KEEP");
+    const bool keep_worst = keep && strcmp(keep, "worst") == 0;
     VectorSet best;
     best.u = c->u_alloc; best.q = c->q_alloc; best.g[0] = c->g_alloc[0]; best.g[1] = c->g_alloc[1];
     best.d[0] = c->d_alloc[0]; best.d[1] = c->d_alloc[1];
@@ -1439,8 +1442,8 @@ static int choose_placement(cg_ctx *c)
         double ms = 0.0;
         int pf = 0;
         rc = cost(&ms, &pf);
-        if (getenv("CG_DEBUG_PLACEMENT")) fprintf(stderr, "placement draw %d: %.3f ms per two iterations (best so far %.3f)\n", k, ms, best_ms);
-        if (rc == CG_OK && ms < 0.995 * best_ms) { rejected[nrej++] = best; best = v; best_ms = ms; best_pf = pf; }
+        if (getenv("CG_DEBUG_PLACEMENT")) fprintf(stderr, "placement draw %d: %.3f ms per two iterations (kept so far %.3f)\n", k, ms, best_ms);
+        if (rc == CG_OK && (keep_worst ? ms > best_ms : ms < 0.995 * best_ms)) { rejected[nrej++] = best; best = v; best_ms = ms; best_pf = pf; }
         else rejected[nrej++] = v;
     }
     adopt_vectors(c, best);
