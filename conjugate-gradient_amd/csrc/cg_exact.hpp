@@ -375,8 +375,10 @@ constexpr int kSub = 128;
 // path, by rows only) and lie `stride` doubles apart (4: the first member of each record).
 __global__ __launch_bounds__(256) void k_xs_from_sub(const double *__restrict__ sub, long nsub, long nchunks,
                                                      long G, long rows, double *__restrict__ approx,
-                                                     double *__restrict__ gsum, int span = kSub, int stride = 1)
+                                                     double *__restrict__ gsum, int span = kSub, int stride = 1,
+                                                     const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
     double acc = 0.0;
     if (c < nchunks) {
@@ -430,8 +432,10 @@ __global__ __launch_bounds__(256) void k_xs_gsum(double *__restrict__ approx, lo
 // In-place exclusive scan of the group sums, seeded with `start` (or, when `start_dev` is
 // given, with the sum of the nstart device-resident values it points to).  One workgroup.
 __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, long ngroups, double start,
-                                                   const double *start_dev, int nstart, int *zero_me = nullptr)
+                                                   const double *start_dev, int nstart, int *zero_me = nullptr,
+                                                   const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     if (zero_me != nullptr && threadIdx.x == 0) *zero_me = 0;      // the repair list of the speculative path starts empty
     if (start_dev != nullptr) {
         start = 0.0;
@@ -462,8 +466,10 @@ __global__ __launch_bounds__(1024) void k_xs_gscan(double *__restrict__ gsum, lo
 }
 
 // Sum of the (not yet scanned) group sums: this block's approximate total, for the ranks that come after it.
-__global__ __launch_bounds__(1024) void k_xs_total(const double *__restrict__ gsum, long ngroups, double *__restrict__ out)
+__global__ __launch_bounds__(1024) void k_xs_total(const double *__restrict__ gsum, long ngroups, double *__restrict__ out,
+                                                   const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     __shared__ double wave_tot[16];
     double mine = 0.0;
     for (long g = threadIdx.x; g < ngroups; g += 1024) mine += gsum[g];
@@ -557,8 +563,9 @@ __global__ __launch_bounds__(256) void k_sp_select(const UnitRec *__restrict__ r
                                                    double *__restrict__ hyp, double rho, const double *rho_dev, long G,
                                                    long rows, const double *__restrict__ approx,
                                                    const double *__restrict__ goff, Summary *__restrict__ chunks,
-                                                   int *__restrict__ fixlist, int *__restrict__ nfix)
+                                                   int *__restrict__ fixlist, int *__restrict__ nfix, const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     constexpr int kUnits = kChunk / kUnit;
     if (rho_dev != nullptr) rho = *rho_dev;                     // the prediction the producing kernel scaled the hypotheses by
     const int lane = threadIdx.x & 63;
@@ -619,8 +626,10 @@ __global__ __launch_bounds__(256) void k_sp_select(const UnitRec *__restrict__ r
 template <class Src>
 __global__ __launch_bounds__(256) void k_sp_fix(const Src src_in, long count, const int *__restrict__ fixlist,
                                                 const int *__restrict__ nfix, const double *__restrict__ approx,
-                                                const double *__restrict__ goff, Summary *__restrict__ chunks)
+                                                const double *__restrict__ goff, Summary *__restrict__ chunks,
+                                                const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     __shared__ __attribute__((aligned(16))) double T[4][Src::kLds];
     Src src = src_in;
     src.prepare();
@@ -667,8 +676,10 @@ __device__ __forceinline__ bool likely_fails(const Summary &c, double guess)
 // chunk sums inside the group / approximate accumulator at the group's start.
 __global__ __launch_bounds__(256) void k_xs_group(const Summary *__restrict__ in, long nin, Summary *__restrict__ out,
                                                   long nout, const double *__restrict__ approx,
-                                                  const double *__restrict__ goff, unsigned long long *__restrict__ marks)
+                                                  const double *__restrict__ goff, unsigned long long *__restrict__ marks,
+                                                  const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nout) return;
@@ -796,10 +807,11 @@ constexpr int kEntry = kChunk + 64 * kPieceDoubles;   // doubles per entry of th
 // marked chunk is three range tests on wave-uniform values and sixteen additions: no ballot, no lane reads.  The walk
 // still judges every summary by the TRUE accumulator, and takes the chunk apart the general way (refine) if any
 // test fails.
-//   [0..2] D, mn, mx of pieces [0, f) under e_g   [3] low word: f | flags << 8
+//   [0..2] D, mn, mx of pieces [0, f) under e_g   [3] low word: f | flags << 8, high word: e_g
 //   [4..19] the products of piece f                [20..28] D, mn, mx of pieces (f, 64) under e_g - 1, e_g, e_g + 1
 //   [32..35] the summary of the stretch of chunks before the entry's chunk (D, mn, mx, bad / e)
 constexpr int kBrief = 36;
+constexpr int kStretchEmpty = 2;       // high word of [35]: there are no chunks between the previous entry's chunk and this one
 constexpr int kBriefNoFast = 1;        // flags: the runs are not prepared (no usable e_g, ragged chunk, huge sums)
 constexpr int kBriefAfterBad = 2;      // << h: the run behind piece f is unusable under hypothesis h
 constexpr int kBriefNoBefore = 16;     // f == 0
@@ -941,6 +953,52 @@ __device__ __forceinline__ Summary stretch_summary(const Summary *__restrict__ c
     return compose(acc, range_compose(chunks, gb * kGroup, b, lane));
 }
 
+// One entry of the plan applied to the accumulator s from its brief B (kBrief doubles, wave-uniform values, in LDS or in
+// global memory): first the stretch of chunks before the entry's chunk, then the chunk the prepared way.  Either returns
+// false -- and leaves s untouched -- when its test fails for the true accumulator; the caller then does that part with
+// the chunk summaries / the staged products, which only the rank that owns the data can.
+__device__ __forceinline__ bool brief_stretch(const double *B, double &s)
+{
+    Summary st;
+    st.D = B[32]; st.mn = B[33]; st.mx = B[34];
+    st.e = uniform(__double2loint(B[35])); st.bad = uniform(__double2hiint(B[35])) & 1;
+    const int es = uniform(exponent_of(s));
+    const double S = (es == kNoExp) ? 0.0 : ldexp(s, 52 - es);
+    if (!uniform((int)holds(st, es, S, (s == 0.0) && signbit(s)))) return false;
+    if (st.e != kAnyExp) s = ldexp(S + st.D, es - 52);      // exact: integers below 2^53
+    return true;
+}
+
+__device__ __forceinline__ bool brief_chunk(const double *B, int e_g, double &s)
+{
+    const int meta = uniform(__double2loint(B[3])), fl = meta >> 8;
+    const int es = uniform(exponent_of(s));
+    if ((fl & kBriefNoFast) || es == kNoExp || es != e_g) return false;
+    double S = ldexp(s, 52 - es);
+    bool ok = true;
+    if (!(fl & kBriefNoBefore)) {
+        const double a = S + B[1], c = S + B[2];
+        ok = (S > 0.0) ? (a >= 0x1p52 + 1.0) && (c <= 0x1p53 - 1.0) : (c <= -(0x1p52 + 1.0)) && (a >= -(0x1p53 - 1.0));
+        S += B[0];                                            // exact if ok: integers below 2^53
+    }
+    if (!uniform((int)ok)) return false;
+    double t = ldexp(S, es - 52);
+    if (!(fl & kBriefNoPiece)) {
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) t += B[4 + i];
+    }
+    if (fl & kBriefNoAfter) { s = t; return true; }
+    const int es2 = uniform(exponent_of(t)), h2 = es2 - e_g + 1;
+    if (es2 == kNoExp || h2 < 0 || h2 > 2 || ((fl >> (1 + h2)) & 1)) return false;
+    const double *ar = B + 20 + 3 * h2;
+    const double D = ar[0], mn = ar[1], mx = ar[2];
+    const double S2 = ldexp(t, 52 - es2), a = S2 + mn, c = S2 + mx;
+    const bool ok2 = (S2 > 0.0) ? (a >= 0x1p52 + 1.0) && (c <= 0x1p53 - 1.0) : (c <= -(0x1p52 + 1.0)) && (a >= -(0x1p53 - 1.0));
+    if (!uniform((int)ok2)) return false;
+    s = ldexp(S2 + D, es2 - 52);
+    return true;
+}
+
 // The plan: the marked chunks (k_xs_group) in index order, at most kPlanCap of them, and for each an entry of
 // kEntry doubles in `dump`: the kChunk products of chunk plist[k], lane-major as chunk16 delivers them; per lane
 // the prepared piece summaries (Pieces); and the summary of the whole stretch of chunks between the previous
@@ -955,8 +1013,10 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
                                                  const unsigned long long *__restrict__ marks,
                                                  long ngroups, const double *__restrict__ approx,
                                                  const double *__restrict__ goff, int *__restrict__ plist,
-                                                 int *__restrict__ pexp, int *__restrict__ pn, double *__restrict__ dump)
+                                                 int *__restrict__ pexp, int *__restrict__ pn, double *__restrict__ dump,
+                                                 const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     __shared__ __attribute__((aligned(16))) double T[4][Src::kLds];
     __shared__ int clist[kPlanCap];
     __shared__ int wave_tot[4];
@@ -1001,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
             if (lane == 0) {
                 xv2 *ps = reinterpret_cast<xv2 *>(brief + 32);
                 xv2 v0, v1;
-                v0.x = st.D; v0.y = st.mn; v1.x = st.mx; v1.y = __hiloint2double(st.bad & 1, st.e);
+                v0.x = st.D; v0.y = st.mn; v1.x = st.mx; v1.y = __hiloint2double((st.bad & 1) | (from >= to ? kStretchEmpty : 0), st.e);
                 ps[0] = v0; ps[1] = v1;
             }
             continue;
@@ -1076,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_xs_plan(const Src src_in, long count, c
                 }
             }
         }
-        bf[3] = __hiloint2double(0, f | (bflags << 8));
+        bf[3] = __hiloint2double(e_g, f | (bflags << 8));       // (high word: the predicted binade, for a walk that has only the briefs)
         if (lane < 15) {                                  // lane i stores doubles 2i, 2i + 1
             xv2 v;
             v.x = bf[0]; v.y = bf[1];
@@ -1146,8 +1206,10 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                                                 const Summary *__restrict__ groups, long ngroups, double start,
                                                 const double *start_dev, double *result, long *stats,
                                                 const int *__restrict__ plist, const int *__restrict__ pexp,
-                                                const int *__restrict__ pn, const double *__restrict__ dump)
+                                                const int *__restrict__ pn, const double *__restrict__ dump,
+                                                const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     __shared__ __attribute__((aligned(16))) double T[Src::kLds];
     __shared__ int lst[kPlanCap], lexp[kPlanCap];
     __shared__ __attribute__((aligned(16))) double lbrief[kBriefBatch * kBrief];
@@ -1194,62 +1256,18 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                 store_batch();
                 fetch_batch(k + kBriefBatch);
             }
-            const xv2 *b = reinterpret_cast<const xv2 *>(lbrief + (k & (kBriefBatch - 1)) * kBrief);
             const long end = (k < n) ? (long)uniform(lst[k]) : nchunks;
-            if (pos < end) {
-                Summary st;
-                const xv2 s0 = b[16], s1 = b[17];
-                st.D = s0.x; st.mn = s0.y; st.mx = s1.x;
-                st.e = uniform(__double2loint(s1.y)); st.bad = uniform(__double2hiint(s1.y));
-                const int es = uniform(exponent_of(s));
-                const double S = (es == kNoExp) ? 0.0 : ldexp(s, 52 - es);
-                if (uniform((int)holds(st, es, S, (s == 0.0) && signbit(s)))) {
-                    if (st.e != kAnyExp) s = ldexp(S + st.D, es - 52);      // exact: integers below 2^53
-                } else {
-                    ++n_groups;
-                    s = walk_range(src, count, chunks, nchunks, groups, pos, end, s, lane, T, n_groups, n_chunks, tally);
-                }
+            const double *B = lbrief + (k & (kBriefBatch - 1)) * kBrief;
+            if (pos < end && !brief_stretch(B, s)) {
+                ++n_groups;
+                s = walk_range(src, count, chunks, nchunks, groups, pos, end, s, lane, T, n_groups, n_chunks, tally);
             }
             if (k == n) break;
             const long lo = end * kChunk, hi = (lo + kChunk < count) ? lo + kChunk : count;
             const int e_g = uniform(lexp[k]);
             ++n_chunks; ++n_planned;
             // The prepared way: a run of pieces under e_g, one piece literally, a run under the binade reached.
-            bool done = false;
-            {
-                const xv2 b0 = b[0], b1 = b[1];
-                const int meta = uniform(__double2loint(b1.y)), fl = meta >> 8;
-                const int es = uniform(exponent_of(s));
-                if (!(fl & kBriefNoFast) && es != kNoExp && es == e_g) {
-                    double S = ldexp(s, 52 - es);
-                    bool ok = true;
-                    if (!(fl & kBriefNoBefore)) {
-                        const double a = S + b0.y, c = S + b1.x;
-                        ok = (S > 0.0) ? (a >= 0x1p52 + 1.0) && (c <= 0x1p53 - 1.0) : (c <= -(0x1p52 + 1.0)) && (a >= -(0x1p53 - 1.0));
-                        S += b0.x;                                            // exact if ok: integers below 2^53
-                    }
-                    if (uniform((int)ok)) {
-                        double t = ldexp(S, es - 52);
-                        if (!(fl & kBriefNoPiece)) {
-#pragma unroll
-                            for (int i = 0; i < kPerLane / 2; ++i) { const xv2 pp = b[2 + i]; t += pp.x; t += pp.y; }
-                        }
-                        if (fl & kBriefNoAfter) {
-                            s = t; done = true;
-                        } else {
-                            const int es2 = uniform(exponent_of(t)), h2 = es2 - e_g + 1;
-                            if (es2 != kNoExp && h2 >= 0 && h2 <= 2 && !((fl >> (1 + h2)) & 1)) {
-                                const double *ar = lbrief + (k & (kBriefBatch - 1)) * kBrief + 20 + 3 * h2;
-                                const double D = ar[0], mn = ar[1], mx = ar[2];
-                                const double S2 = ldexp(t, 52 - es2), a = S2 + mn, c = S2 + mx;
-                                const bool ok2 = (S2 > 0.0) ? (a >= 0x1p52 + 1.0) && (c <= 0x1p53 - 1.0)
-                                                            : (c <= -(0x1p52 + 1.0)) && (a >= -(0x1p53 - 1.0));
-                                if (uniform((int)ok2)) { s = ldexp(S2 + D, es2 - 52); done = true; }
-                            }
-                        }
-                    }
-                }
-            }
+            const bool done = brief_chunk(B, e_g, s);
             if (!done) {                               // the general way, from the chunk's start: its staged products and pieces
                 ++n_general;
                 const double *base = dump + (long)k * kEntry;
@@ -1281,13 +1299,84 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
     }
 }
 
+// ---- several ranks: the walk finished on every rank from published briefs ------------------------------------------
+// Row blocks follow one another in the summation order, so the accumulator has to pass through the ranks' blocks in
+// turn.  Handing it from rank to rank costs a collective per rank and dot product.  Instead every rank publishes what
+// a walk over its block needs when nothing unforeseen happens -- its plan's briefs, a few hundred bytes -- in ONE
+// all-gather; rank 0, whose block holds nearly all the binade crossings, walks its own block itself and publishes the
+// exact accumulator it ends with; and every rank then continues that walk through the other ranks' briefs
+// (k_xs_walk_remote), all of them with the same bits.  A brief whose test fails for the true accumulator, or a rank
+// with more entries than fit, cannot be dealt with from afar: the kernel then raises the solve's fault flag, every
+// later kernel returns at once, and the host completes that dot product with the ranks walking in turn (cg_solve).
+constexpr int kRemoteCap = 32;                                   // plan entries a rank can publish
+constexpr int kPayloadHead = 4;                                  // [0] exact accumulator after the block (the rank that walked it itself),
+                                                                 // [1] entries published (-1: too many), [2] the block's q.q (prediction input), [3] spare
+constexpr int kPayload = kPayloadHead + (kRemoteCap + 1) * kBrief;
+
+__global__ __launch_bounds__(64) void k_xs_pack(const int *__restrict__ pn, const double *__restrict__ dump,
+                                                const double *result, const double *__restrict__ partials2, long count2,
+                                                double *__restrict__ slot, const int *skip)
+{
+    if (skip != nullptr && *skip) return;
+    const int lane = threadIdx.x;
+    int n = uniform(*pn);
+    if (n > kPlanCap) n = kPlanCap;
+    double qq = 0.0;
+    for (long k = lane; k < count2; k += 64) qq += partials2[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off, 64);
+    if (lane == 0) {
+        slot[0] = (result != nullptr) ? *result : 0.0;
+        slot[1] = (n <= kRemoteCap) ? (double)n : -1.0;
+        slot[2] = qq;
+        slot[3] = 0.0;
+    }
+    if (n > kRemoteCap) return;
+    const double *briefs = dump + (long)(kPlanCap + 1) * kEntry;
+    for (int i = lane; i < (n + 1) * kBrief; i += 64) slot[kPayloadHead + i] = briefs[i];
+}
+
+// slots: nranks payloads in rank order, the first of them of the rank that walked its own block (slot[0] valid).
+// quiet: a timing rehearsal with one rank standing in for all -- the other slots hold nothing, nothing is raised.
+// fault_every > 0 (test hook): declare every fault_every-th dot product failed, counted over the solve's iterations.
+__global__ __launch_bounds__(64) void k_xs_walk_remote(const double *__restrict__ slots, int nranks, int quiet, Scalars *sc, int phase,
+                                                       long fault_every, double *result, double *qq_out)
+{
+    if (sc->done) return;
+    double s = slots[0], qq = slots[2];
+    bool ok = true;
+    for (int j = 1; j < nranks && ok && !quiet; ++j) {
+        const double *sl = slots + (long)j * kPayload;
+        const int n = uniform((int)sl[1]);
+        qq += sl[2];
+        if (n < 0) { ok = false; break; }
+        for (int k = 0; k <= n; ++k) {
+            const double *B = sl + kPayloadHead + k * kBrief;
+            const bool empty = (uniform(__double2hiint(B[35])) & kStretchEmpty) != 0;
+            if (!empty && !brief_stretch(B, s)) { ok = false; break; }
+            if (k == n) break;
+            if (!brief_chunk(B, uniform(__double2hiint(B[3])), s)) { ok = false; break; }
+        }
+    }
+    if (fault_every > 0 && ((2 * sc->iter + phase) % fault_every) == fault_every - 1) ok = false;
+    if (threadIdx.x != 0) return;
+    if (ok || quiet) {
+        *result = s;
+        *qq_out = qq;
+    } else {
+        sc->fault = 1 + phase;
+        sc->done = 2;
+    }
+}
+
 // Self-check (CG_OPT_STRICT_AUDIT): every usable chunk summary against one recomputed from the products under the
 // same hypothesis -- the sum must be the same integer, the stored extremes must enclose the true ones -- and the
 // result of the plan-driven walk against the hierarchical walk over the same summaries.  Failures are counted.
 template <class Src>
 __global__ __launch_bounds__(256) void k_xs_audit(const Src src_in, long count, const Summary *__restrict__ chunks, long nchunks,
-                                                  unsigned long long *fails)
+                                                  unsigned long long *fails, const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     __shared__ __attribute__((aligned(16))) double T[4][Src::kLds];
     Src src = src_in;
     src.prepare();
@@ -1309,8 +1398,9 @@ __global__ __launch_bounds__(256) void k_xs_audit(const Src src_in, long count, 
         }
     }
 }
-__global__ void k_xs_audit_result(const double *plan, const double *hier, unsigned long long *fails)
+__global__ void k_xs_audit_result(const double *plan, const double *hier, unsigned long long *fails, const int *skip = nullptr)
 {
+    if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     const double a = *plan, b = *hier;
     if (!(a == b || (a != a && b != b))) {
         atomicAdd(fails, 1ull);
@@ -1348,6 +1438,8 @@ struct Workspace {
     double *dump = nullptr;               // their products and prepared pieces (kEntry doubles each), then their briefs (kBrief each)
     unsigned long long *audit = nullptr;  // [0] failures counted by the self-check, [1] scratch (its second result)
     long cap_chunks = 0;
+    const int *skip = nullptr;            // device flag (a solve's Scalars::done), or null: when set, the kernels of the speculative
+                                          // path and the walks return at once and leave the workspace as it is
     // speculative path (reserve_spec): span sums under two hypotheses, the hypotheses of the two dot products of
     // an iteration (they persist from one iteration to the next), the repair list
     double *rec = nullptr;                            // one record of four doubles per unit of cg::kUnit products (UnitRec)
@@ -1476,12 +1568,12 @@ inline void enqueue_levels_and_plan(hipStream_t s, const Workspace &ws, const Sr
 {
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks);
+    hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, s, ws.chunks, nc, ws.groups, ng, ws.approx, ws.goff, ws.marks, ws.skip);
     const long nsup = (ng + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_group, dim3((unsigned)((nsup + 3) / 4)), dim3(256), 0, s, ws.groups, ng, ws.supers, nsup,
-                       (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr);
+                       (const double *)nullptr, (const double *)nullptr, (unsigned long long *)nullptr, ws.skip);
     hipLaunchKernelGGL(k_xs_plan<Src>, dim3(kPlanBlocks), dim3(256), 0, s, src, count, ws.chunks, nc, ws.groups, ws.supers,
-                       ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump);
+                       ws.marks, ng, ws.approx, ws.goff, ws.plist, ws.pexp, ws.pn, ws.dump, ws.skip);
 }
 
 inline void enqueue_summaries(hipStream_t s, const Workspace &ws, const Arrays &a, double start, const double *seed_dev = nullptr,
@@ -1507,13 +1599,13 @@ inline void enqueue_walk(hipStream_t s, const Workspace &ws, const Src &src, lon
     if (count <= 0) {
         hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, 0L, ws.chunks, 0L, ws.groups, 0L,
                            start, start_dev, result, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
-                           (const int *)nullptr, (const double *)nullptr);
+                           (const int *)nullptr, (const double *)nullptr, ws.skip);
         return;
     }
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, start_dev, result, stats, ws.plist, ws.pexp, ws.pn, ws.dump);
+                       start, start_dev, result, stats, ws.plist, ws.pexp, ws.pn, ws.dump, ws.skip);
 }
 
 inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,
@@ -1537,8 +1629,8 @@ inline void spec_approx(hipStream_t s, const Workspace &ws, long G, long rows, d
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (const double *)ws.rec, count / kUnit,
-                       nc, G, rows, ws.approx, ws.goff, (int)kUnit, 4);
-    if (total_out) hipLaunchKernelGGL(k_xs_total, dim3(1), dim3(1024), 0, s, ws.goff, ng, total_out);
+                       nc, G, rows, ws.approx, ws.goff, (int)kUnit, 4, ws.skip);
+    if (total_out) hipLaunchKernelGGL(k_xs_total, dim3(1), dim3(1024), 0, s, ws.goff, ng, total_out, ws.skip);
 }
 
 template <class Src>
@@ -1548,11 +1640,11 @@ inline void spec_summaries(hipStream_t s, const Workspace &ws, const Src &src, l
     const long count = G * rows;
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, seed_dev, nseed, ws.nfix);
+    hipLaunchKernelGGL(k_xs_gscan, dim3(1), dim3(1024), 0, s, ws.goff, ng, start, seed_dev, nseed, ws.nfix, ws.skip);
     const long nwave = ((rows + 63) / 64) * (G / kChunk);
     hipLaunchKernelGGL(k_sp_select, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const UnitRec *>(ws.rec),
-                       nonneg ? 1 : 0, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix);
-    hipLaunchKernelGGL(k_sp_fix<Src>, dim3(256), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks);
+                       nonneg ? 1 : 0, ws.hyp[which], 1.0, rho_dev, G, rows, ws.approx, ws.goff, ws.chunks, ws.fixlist, ws.nfix, ws.skip);
+    hipLaunchKernelGGL(k_sp_fix<Src>, dim3(256), dim3(256), 0, s, src, count, ws.fixlist, ws.nfix, ws.approx, ws.goff, ws.chunks, ws.skip);
     enqueue_levels_and_plan(s, ws, src, count);
 }
 
@@ -1566,9 +1658,9 @@ inline void enqueue_audit(hipStream_t s, const Workspace &ws, const Src &src, lo
     double *second = reinterpret_cast<double *>(ws.audit + 1);
     hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
                        start, start_dev, second, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
-                       (const int *)nullptr, (const double *)nullptr);
-    hipLaunchKernelGGL(k_xs_audit<Src>, dim3(256), dim3(256), 0, s, src, count, ws.chunks, nc, ws.audit);
-    hipLaunchKernelGGL(k_xs_audit_result, dim3(1), dim3(1), 0, s, result, second, ws.audit);
+                       (const int *)nullptr, (const double *)nullptr, ws.skip);
+    hipLaunchKernelGGL(k_xs_audit<Src>, dim3(256), dim3(256), 0, s, src, count, ws.chunks, nc, ws.audit, ws.skip);
+    hipLaunchKernelGGL(k_xs_audit_result, dim3(1), dim3(1), 0, s, result, second, ws.audit, ws.skip);
 }
 
 // One rank: all three in a row.

@@ -57,8 +57,9 @@ struct Scalars {
     double stop;        // stop when q1 <= stop (0 = never)
     double dot;         // result slot of the stand-alone dot entry point
     long long iter;     // iterations completed
-    int done;           // set by k_finish when the stop rule fires
-    int pad;
+    int done;           // 1: set by k_finish when the stop rule fires; 2: a dot product could not be completed on the
+                        // fast path (`fault`) -- either way every later kernel returns at once, and the host looks
+    int fault;          // 1 + which dot product (0 = d.q, 1 = g.g) of iteration `iter` is waiting to be completed the slow way
     double tau_ring[8]; // tau of iteration i at [i & 7]: deferred u updates read them later
     long long u_applied;// iterations whose tau*d has been added into u (lean schedule defers them)
     long long iter_base;// value of `iter` when the current solve began: a solve that continues the previous one

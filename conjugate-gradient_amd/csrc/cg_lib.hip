@@ -269,6 +269,11 @@ struct cg_ctx {
                                           // memory) has the fork and join cost more than they hide; bench.py times both and keeps the faster
     int rehearse = 0;                     // single rank with an RCCL communicator: issue the multi-rank traffic anyway
     int resum_q0 = 0;                     // a solve that continues the previous one sums q0 = g.g again (cg.c:55) instead of taking it over
+    int strict_chain = 1;                 // several ranks, strict order, lean schedule: 1 = the ranks publish their plans' briefs and every
+                                          // rank finishes the walk (two collectives per dot product); 0 = the ranks walk in turn
+    bool strict_safe = false;             // the iteration being enqueued completes a faulted dot product: ranks walk in turn
+    long fault_every = 0;                 // test hook: the published walk declares every n-th dot product failed
+    long strict_faults = 0;               // dot products completed by the ranks walking in turn after the published walk gave up
 
     // device state
     hipStream_t stream = nullptr;
@@ -463,11 +468,30 @@ bool strict_speculative(const cg_ctx *c, const TileGeom &t)
 // all-gather), its summaries and its plan -- all ranks at once; only the walks go in turn, the exact accumulator
 // handed from rank to rank by one all-gather of a double per round.  approx(total_out), summaries(seed, nseed) and
 // walk(start_dev, result) enqueue the three phases; *result_at is where the final value is on this rank.
+// The last phase alone: the ranks' walks in turn, rank k continuing from rank k-1's exact value.
+template <class FW>
+int strict_chain_walks(cg_ctx *c, FW walk, const double **result_at)
+{
+    hipStream_t s = c->stream;
+    double *gb = c->comm->gather_buf();
+    for (int k = 0; k < c->nranks; ++k) {
+        if (k == c->rank) {
+            walk(k > 0 ? (const double *)(gb + (k - 1)) : (const double *)nullptr, gb + c->rank);
+            HIPCHK(hipGetLastError());
+        }
+        CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+    }
+    // a single rank rehearsing the traffic of `rehearse` ranks: the all-gathers the other ranks' turns would bring
+    for (int k = c->nranks; k < c->rehearse; ++k) CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+    *result_at = gb + (c->nranks - 1);
+    return CG_OK;
+}
+
 template <class FA, class FS, class FW>
 int strict_rank_chain(cg_ctx *c, FA approx, FS summaries, FW walk, const double **result_at)
 {
     hipStream_t s = c->stream;
-    if (c->nranks == 1) {
+    if (c->nranks == 1 && c->rehearse <= 1) {
         approx((double *)nullptr);
         summaries((const double *)nullptr, 0);
         walk((const double *)nullptr, c->strict_slot);
@@ -481,14 +505,40 @@ int strict_rank_chain(cg_ctx *c, FA approx, FS summaries, FW walk, const double 
     CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
     summaries((const double *)gb, c->rank);
     HIPCHK(hipGetLastError());
-    for (int k = 0; k < c->nranks; ++k) {
-        if (k == c->rank) {
-            walk(k > 0 ? (const double *)(gb + (k - 1)) : (const double *)nullptr, gb + c->rank);
-            HIPCHK(hipGetLastError());
-        }
-        CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
-    }
-    *result_at = gb + (c->nranks - 1);
+    return strict_chain_walks(c, walk, result_at);
+}
+
+// The same dot product with O(1) collectives (lean schedule with span sums only; cg_exact.hpp, k_xs_walk_remote): after
+// the approximate totals (one all-gather) every rank builds its plan; rank 0 -- whose block holds nearly all binade
+// crossings -- walks its own block; one all-gather publishes rank 0's exact accumulator and every rank's briefs; every
+// rank finishes the walk through the other ranks' briefs.  phase: 0 = d.q, 1 = g.g (what a fault reports).  partials2 /
+// count2: this rank's q.q partial sums (prediction input, summed over the ranks on the way), or null.  The result lands
+// in strict_slot[0], the grid's q.q in strict_slot[1].  If a brief does not hold for the true accumulator the kernel
+// raises Scalars::done = 2 instead, and cg_solve completes the dot product with strict_chain_walks.
+template <class FA, class FS, class FW>
+int strict_chain_published(cg_ctx *c, FA approx, FS summaries, FW walk, int phase, const double *partials2, long count2,
+                           const double **result_at)
+{
+    hipStream_t s = c->stream;
+    const bool self = c->comm->self_only();             // timing rehearsal: this rank stands in for all
+    double *gb = c->comm->gather_buf();
+    approx(gb + c->rank);
+    HIPCHK(hipGetLastError());
+    CGCHK(comm_rc(c, c->comm->allgather_scalar(s)));
+    summaries((const double *)gb, c->rank);
+    HIPCHK(hipGetLastError());
+    const bool walker = self || c->rank == 0;
+    if (walker) walk((const double *)nullptr, c->strict_slot);
+    double *slots = c->comm->block_buf();
+    static_assert(cg::exact::kPayload <= cg::Comm::kBlockCap, "a rank's published briefs must fit its slice of the all-gather buffer");
+    hipLaunchKernelGGL(cg::exact::k_xs_pack, dim3(1), dim3(64), 0, s, c->xs.pn, c->xs.dump, walker ? (const double *)c->strict_slot : (const double *)nullptr,
+                       partials2, count2, slots + (long)c->rank * cg::exact::kPayload, c->xs.skip);
+    HIPCHK(hipGetLastError());
+    CGCHK(comm_rc(c, c->comm->allgather_block(s, cg::exact::kPayload)));
+    hipLaunchKernelGGL(cg::exact::k_xs_walk_remote, dim3(1), dim3(64), 0, s, self ? slots + (long)c->rank * cg::exact::kPayload : slots,
+                       self ? 1 : c->nranks, self ? 1 : 0, c->sc, phase, c->fault_every, c->strict_slot, c->strict_slot + 1);
+    HIPCHK(hipGetLastError());
+    *result_at = c->strict_slot;
     return CG_OK;
 }
 
@@ -666,20 +716,22 @@ int enqueue_lean_iteration(cg_ctx *c)
         src.d = c->d[in]; src.g = c->g; src.sc = c->sc; src.coef = c->coef;
         src.G = c->G; src.rows = c->rows; src.row0 = c->row0; src.count = c->count; src.beta = 0.0;
         const double *at = nullptr;
-        CGCHK(strict_rank_chain(
-            c, [&](double *total) { cg::exact::spec_approx(s, c->xs, c->G, c->rows, total); },
-            [&](const double *seed, int nseed) {
-                cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, seed, nseed);
-            },
-            [&](const double *start_dev, double *result) {
-                cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats);
-                if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
-            },
-            &at));
-        // (the growth prediction for g.g needs q.q of the whole grid: one rank has it, several fall back on beta)
+        auto f_approx = [&](double *total) { cg::exact::spec_approx(s, c->xs, c->G, c->rows, total); };
+        auto f_summ = [&](const double *seed, int nseed) {
+            cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, seed, nseed);
+        };
+        auto f_walk = [&](const double *start_dev, double *result) {
+            cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats);
+            if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
+        };
+        const bool published = c->multi() && c->strict_chain && !c->strict_safe && !c->strict_audit;
+        if (published) CGCHK(strict_chain_published(c, f_approx, f_summ, f_walk, 0, a.partials2, tq.ntiles, &at));
+        else CGCHK(strict_rank_chain(c, f_approx, f_summ, f_walk, &at));
+        // the growth prediction for g.g needs q.q of the whole grid: this rank's partial sums, or (published walk) the
+        // ranks' sums added up on the way; the ranks walking in turn fall back on the last beta
+        const double *qq = published ? at + 1 : (c->nranks == 1 ? (const double *)a.partials2 : (const double *)nullptr);
         hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_dq, tq.ntiles, at, 1, c->sc, 0, 0.0,
-                           c->hist, c->hist_cap, c->nranks == 1 ? (const double *)a.partials2 : (const double *)nullptr,
-                           c->nranks == 1 ? tq.ntiles : -1L);
+                           c->hist, c->hist_cap, qq, published ? 1L : (c->nranks == 1 ? tq.ntiles : -1L));
     } else {
         if (strict) {
             a.q = c->q; a.store_products = 1;
@@ -729,22 +781,60 @@ int enqueue_lean_iteration(cg_ctx *c)
         const int vec = ((reinterpret_cast<uintptr_t>(b.g_out)) & 15) == 0 ? 1 : 0;
         const cg::exact::SrcArrays src{b.g_out, b.g_out, c->count, vec};
         const double *at = nullptr;
-        CGCHK(strict_rank_chain(
-            c, [&](double *total) { cg::exact::spec_approx(s, c->xs, c->G, c->rows, total); },
-            [&](const double *seed, int nseed) {
-                cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, seed, nseed);
-            },
-            [&](const double *start_dev, double *result) {
-                cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats + 8);
-                if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
-            },
-            &at));
+        auto f_approx = [&](double *total) { cg::exact::spec_approx(s, c->xs, c->G, c->rows, total); };
+        auto f_summ = [&](const double *seed, int nseed) {
+            cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, seed, nseed);
+        };
+        auto f_walk = [&](const double *start_dev, double *result) {
+            cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats + 8);
+            if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
+        };
+        if (c->multi() && c->strict_chain && !c->strict_safe && !c->strict_audit)
+            CGCHK(strict_chain_published(c, f_approx, f_summ, f_walk, 1, (const double *)nullptr, 0L, &at));
+        else
+            CGCHK(strict_rank_chain(c, f_approx, f_summ, f_walk, &at));
         hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_gg, n_gg, at, 1, c->sc, with_u ? 1 : 4, 0.0,
                            c->hist, c->hist_cap);
     } else {
         CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
     }
     c->dcur = out;
+    c->set_gcur(c->gcur ^ 1);
+    c->lean_pending = with_u ? 0 : 1;
+    return CG_OK;
+}
+
+// A lean iteration whose published walk (strict_chain_published) gave up on dot product `phase` (0 = d.q, 1 = g.g): every
+// kernel launched after it returned at once, so the vectors, the device scalars and the strict-order workspace are as that
+// dot product left them, and the context's buffer roles have been set back to those before the iteration.  Complete the
+// iteration with the ranks walking in turn.  Collective: every rank saw the same fault (the walk that raised it ran on
+// identical data everywhere).
+int recover_faulted_iteration(cg_ctx *c, int phase)
+{
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemsetAsync(&c->sc->done, 0, 2 * sizeof(int), s));       // done and fault
+    ++c->strict_faults;
+    if (phase == 0) {
+        // pass 1 only reads: the whole iteration once more, its dot products handed from rank to rank
+        c->strict_safe = true;
+        const int rc = enqueue_lean_iteration(c);
+        c->strict_safe = false;
+        return rc;
+    }
+    // pass 2 has run (the new direction and gradient are in the other buffers, u is updated where it was due); the
+    // summaries and the plan of g'.g' are in the workspace: only the ordered walks and the scalar step are missing
+    const bool with_u = c->lean_pending == 1;
+    double *g_out = c->g_buf[c->gcur ^ 1];
+    const int vec = ((reinterpret_cast<uintptr_t>(g_out)) & 15) == 0 ? 1 : 0;
+    const cg::exact::SrcArrays src{g_out, g_out, c->count, vec};
+    const double *at = nullptr;
+    CGCHK(strict_chain_walks(
+        c, [&](const double *start_dev, double *result) { cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats + 8); },
+        &at));
+    hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, c->partials + c->npart, 0L, at, 1, c->sc, with_u ? 1 : 4, 0.0,
+                       c->hist, c->hist_cap);
+    HIPCHK(hipGetLastError());
+    c->dcur ^= 1;
     c->set_gcur(c->gcur ^ 1);
     c->lean_pending = with_u ? 0 : 1;
     return CG_OK;
@@ -1532,6 +1622,7 @@ int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, 
     if (rc != CG_OK) { cg_destroy(c); return rc; }
     (void)hipMemset(c->sc, 0, sizeof(Scalars));
     (void)hipStreamSynchronize(nullptr);
+    c->xs.skip = &c->sc->done;                           // the strict-order kernels stand still behind a fired stop rule or a fault
     rc = choose_placement(c);
     if (rc != CG_OK) { cg_destroy(c); return rc; }
     *out = c;
@@ -1597,11 +1688,16 @@ int cg_set_option(cg_ctx *c, int key, long value)
         c->strict_blocks = value; break;
     case CG_OPT_OVERLAP: c->overlap = value ? 1 : 0; break;
     case CG_OPT_RESUM_Q0: c->resum_q0 = value ? 1 : 0; break;
+    case CG_OPT_STRICT_CHAIN: c->strict_chain = value ? 1 : 0; break;
+    case CG_OPT_STRICT_FAULT_EVERY:
+        if (value < 0) return fail(CG_ERR_ARG, "fault period must be >= 0");
+        c->fault_every = value; break;
     case CG_OPT_STRICT_SPEC: c->strict_spec = value ? 1 : 0; break;
     case CG_OPT_STRICT_AUDIT: c->strict_audit = value ? 1 : 0; drop_graph(c); break;
     case CG_OPT_COMM_REHEARSAL:
         if (value && c->nranks != 1) return fail(CG_ERR_ARG, "the communication rehearsal is for single-rank contexts");
-        c->rehearse = value ? 1 : 0; break;
+        if (value < 0 || value > 64) return fail(CG_ERR_ARG, "rehearsal rank count out of range");
+        c->rehearse = (int)value; break;
     case CG_OPT_STRICT_IMPL:
         if (value < kStrictAuto || value > kStrictParallel) return fail(CG_ERR_ARG, "strict implementation must be 1, 2 or 3");
         c->strict_impl = (int)value; break;
@@ -1637,6 +1733,9 @@ int cg_get_option(cg_ctx *c, int key, long *value)
     case CG_OPT_TILE_WGS: *value = ctx_geom(c).max_wgs; break;
     case CG_OPT_OVERLAP: *value = c->overlap; break;
     case CG_OPT_RESUM_Q0: *value = c->resum_q0; break;
+    case CG_OPT_STRICT_CHAIN: *value = c->strict_chain; break;
+    case CG_OPT_STRICT_FAULT_EVERY: *value = c->fault_every; break;
+    case CG_OPT_STRICT_FAULTS: *value = c->strict_faults; break;
     case CG_OPT_STRICT_SPEC: *value = c->strict_spec; break;
     case CG_OPT_STRICT_AUDIT: {                         // failures the self-check has counted so far (0 when it is off)
         unsigned long long n = 0;
@@ -1822,55 +1921,69 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         }
         CGCHK(enqueue_dot_finish(c, c->g, c->g, p0, fb, cont ? 6 : 2, rtol));
     }
-    const int dcur_start = c->dcur, gcur_start = c->gcur, pend_start = c->lean_pending;
+    const int dcur_start = c->dcur, gcur_start = c->gcur;
+    // Buffer roles after `executed` iterations of this solve (those skipped behind a fired stop rule or a fault moved
+    // nothing): the leading iteration works in place, every other fused / lean iteration flips d (lean: and g).
+    auto roles_after = [&](long executed, const Scalars &h) {
+        if (sched != CG_SCHED_CLASSIC) {
+            const long moved = executed - (lead && executed >= 1 ? 1 : 0);
+            c->dcur = dcur_start ^ (int)(moved & 1);
+            if (sched == CG_SCHED_LEAN) {
+                c->set_gcur(gcur_start ^ (int)(moved & 1));
+                c->lean_pending = (int)(h.iter - h.u_applied);
+                c->q_valid = false;
+            } else {
+                c->set_gcur(gcur_start);
+                c->lean_pending = 0;
+                c->q_valid = (sched == CG_SCHED_FUSED);
+            }
+            if (executed >= 1) c->pending_dupdate = true;
+        } else {
+            c->dcur = dcur_start;
+            c->set_gcur(gcur_start);
+            if (c->nranks > 1 && executed >= 1) c->d_halo_stale = true;
+        }
+    };
     long launched = 0;
     bool stopped = false;
     if (lead) { CGCHK(enqueue_iteration(c, true)); launched = 1; }
-    while (launched < max_iters && !stopped) {
-        if (glen > 0 && max_iters - launched >= glen && graph->dcur == c->dcur && graph->gcur == c->gcur &&
-            graph->pend == c->lean_pending) {
-            HIPCHK(hipGraphLaunch(graph->exec, s));
-            launched += glen;                           // an even number of iterations: the roles are as before
-        } else {
-            CGCHK(enqueue_iteration(c, false));
-            launched += 1;
+    for (;;) {
+        while (launched < max_iters && !stopped) {
+            if (glen > 0 && max_iters - launched >= glen && graph->dcur == c->dcur && graph->gcur == c->gcur &&
+                graph->pend == c->lean_pending) {
+                HIPCHK(hipGraphLaunch(graph->exec, s));
+                launched += glen;                           // an even number of iterations: the roles are as before
+            } else {
+                CGCHK(enqueue_iteration(c, false));
+                launched += 1;
+            }
+            if (rtol > 0 && (launched % 64 < (glen > 0 ? glen : 1))) {
+                // Stop rule: look at the device flag now and then.  Iterations launched
+                // after it fired are no-ops on the device, so polling lazily costs
+                // nothing but empty launches.
+                HIPCHK(hipMemcpyAsync(c->host_sc, c->sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                stopped = c->host_sc->done != 0;
+            }
         }
-        if (rtol > 0 && (launched % 64 < (glen > 0 ? glen : 1))) {
-            // Stop rule: look at the device flag now and then.  Iterations launched
-            // after it fired are no-ops on the device, so polling lazily costs
-            // nothing but empty launches.
-            HIPCHK(hipMemcpyAsync(c->host_sc, c->sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            stopped = c->host_sc->done != 0;
-        }
+        HIPCHK(hipMemcpyAsync(c->host_sc, c->sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (c->host_sc->done != 2) break;
+        // A published walk gave up (several ranks, strict order): the iteration it belongs to is completed with the ranks
+        // walking in turn, and the solve goes on behind it.
+        const Scalars h = *c->host_sc;
+        const long executed = (long)(h.iter - h.iter_base);
+        if (sched != CG_SCHED_LEAN || h.fault < 1 || h.fault > 2) return fail(CG_ERR_STATE, "unexpected fault state %d on the device", h.fault);
+        roles_after(executed, h);
+        CGCHK(recover_faulted_iteration(c, h.fault - 1));
+        launched = executed + 1;
+        stopped = false;
     }
-    HIPCHK(hipMemcpyAsync(c->host_sc, c->sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();
 
     const Scalars &h = *c->host_sc;
     const long executed = (long)(h.iter - h.iter_base);   // iterations of this solve that really ran
-    // Buffer roles after `executed` iterations (those skipped behind a fired stop rule moved nothing): the
-    // leading iteration works in place, every other fused / lean iteration flips d (lean: and g).
-    if (sched != CG_SCHED_CLASSIC) {
-        const long moved = executed - (lead && executed >= 1 ? 1 : 0);
-        c->dcur = dcur_start ^ (int)(moved & 1);
-        if (sched == CG_SCHED_LEAN) {
-            c->set_gcur(gcur_start ^ (int)(moved & 1));
-            c->lean_pending = (int)(h.iter - h.u_applied);
-            c->q_valid = false;
-        } else {
-            c->set_gcur(gcur_start);
-            c->lean_pending = 0;
-            c->q_valid = (sched == CG_SCHED_FUSED);
-        }
-        if (executed >= 1) c->pending_dupdate = true;
-        (void)pend_start;
-    } else {
-        c->dcur = dcur_start;
-        c->set_gcur(gcur_start);
-        if (c->nranks > 1 && executed >= 1) c->d_halo_stale = true;
-    }
+    roles_after(executed, h);
     if (c->lean_pending < 0 || c->lean_pending > 1) return fail(CG_ERR_STATE, "lean schedule: %d u updates owed", c->lean_pending);
     c->live = true;
     c->hist_len = executed < c->hist_cap ? executed : c->hist_cap;

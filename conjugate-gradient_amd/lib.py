@@ -22,6 +22,7 @@ OPT_STRICT_BLOCKS = 12
 OPT_OVERLAP = 13
 OPT_COMM_REHEARSAL = 14
 OPT_RESUM_Q0 = 19
+OPT_STRICT_CHAIN, OPT_STRICT_FAULT_EVERY, OPT_STRICT_FAULTS = 20, 21, 22
 OPT_STRICT_SPEC = 15
 OPT_STRICT_MISSES = 16
 OPT_STRICT_EVENTS = 17

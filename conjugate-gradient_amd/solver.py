@@ -207,7 +207,7 @@ class CGSolver:
         if strict_spec is not None:
             self.set_option(_l.OPT_STRICT_SPEC, 1 if strict_spec else 0)
         if comm_rehearsal is not None:
-            self.set_option(_l.OPT_COMM_REHEARSAL, 1 if comm_rehearsal else 0)
+            self.set_option(_l.OPT_COMM_REHEARSAL, int(comm_rehearsal))     # True / P: rehearse the traffic of P ranks
         return self
 
     def set_stencil(self, coef):

@@ -194,9 +194,21 @@ typedef struct cg_ctx cg_ctx;
 #define CG_OPT_RESUM_Q0    19  /* 1 = a cg_solve that continues the previous one (see cg_solve) still begins with the dot
                                   product q0 = g.g of cg.c:55 instead of taking q1 over: the reference's timed region
                                   (cg.c:50-55) with warm vectors.  Strict order: the same bits either way.  Default 0 */
-#define CG_OPT_COMM_REHEARSAL 14 /* single-rank context with cg_comm_init: 1 = issue the per-iteration traffic of a
-                                  multi-rank solve anyway (a grouped send/receive of two rows to the rank itself, the
-                                  two all-gathers of the partial sums), to put a number on its cost with one GPU */
+#define CG_OPT_STRICT_CHAIN 20 /* several ranks, CG_REDUCE_STRICT, lean schedule: how the one accumulator passes through the ranks'
+                                  row blocks.  1 (default) = every rank publishes the briefs of its plan (what a walk over its
+                                  block needs when nothing unforeseen happens) in one all-gather, rank 0 walks its own block, and
+                                  every rank finishes the walk from there: two collectives per dot product whatever the rank
+                                  count; a dot product for which a brief does not hold is completed by the ranks walking in turn
+                                  (cg_solve notices, nothing is lost).  0 = the ranks always walk in turn (one collective per rank
+                                  and dot product).  Same bits */
+#define CG_OPT_STRICT_FAULT_EVERY 21 /* test hook for CG_OPT_STRICT_CHAIN: n > 0 declares every n-th dot product (counted as
+                                  2 * iteration + {0: d.q, 1: g.g}) failed on the published walk, so that the completion by
+                                  ranks walking in turn runs; 0 (default) = off */
+#define CG_OPT_STRICT_FAULTS 22 /* read only: dot products the context has completed that way so far */
+#define CG_OPT_COMM_REHEARSAL 14 /* single-rank context with cg_comm_init: P >= 1 = issue the per-iteration traffic of a
+                                  solve on P ranks anyway (a grouped send/receive of two rows to the rank itself, the
+                                  all-gathers of the dot products -- in the strict order with the ranks walking in turn, one
+                                  per rank), to put a number on its cost with one GPU.  The results are not affected */
 #define CG_OPT_TILE_WGS    9   /* cap on workgroups per tiled launch; with more tiles than that each
                                   workgroup walks several tiles in turn.  0 = auto (256 with automatic
                                   tile height, one workgroup per tile with an explicit CG_OPT_TILE_H) */

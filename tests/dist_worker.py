@@ -72,6 +72,10 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast", digest=False):
                     strict_impl={"strict": cg.STRICT_AUTO, "strict_replay": cg.STRICT_REPLAY,
                                  "strict_parallel": cg.STRICT_PARALLEL}[order])
     s.configure(overlap=os.environ.get("CG_TEST_OVERLAP", "1") != "0")   # the split second pass (edge strips first) unless told otherwise
+    if "CG_TEST_STRICT_CHAIN" in os.environ:      # 0: the ranks walk in turn; 1 (the default): published briefs
+        s.set_option(cg.lib.OPT_STRICT_CHAIN, int(os.environ["CG_TEST_STRICT_CHAIN"]))
+    if "CG_TEST_FAULT_EVERY" in os.environ:       # test hook: every n-th dot product is completed by the ranks walking in turn
+        s.set_option(cg.lib.OPT_STRICT_FAULT_EVERY, int(os.environ["CG_TEST_FAULT_EVERY"]))
     s.comm_init_host(tr)
     s.comm_selftest()                             # tagged all-gather and row exchange arrive where they should
     s.init_problem()
@@ -85,7 +89,8 @@ def gpu_rank(tr, cg, n, iters, schedule, rtol, order="fast", digest=False):
             s.configure(schedule=ids[second])
         r = s.solve(iters - iters // 2)
         total, hist, q_init = first.iters + r.iters, np.concatenate([h1, s.history(iters)]), first.q_init
-    out = dict(row0=row0, hist=hist, q1=r.q1, iters=total, converged=int(r.converged), q_init=q_init)
+    out = dict(row0=row0, hist=hist, q1=r.q1, iters=total, converged=int(r.converged), q_init=q_init,
+               faults=s.get_option(cg.lib.OPT_STRICT_FAULTS))
     for key, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
         v = s.vector(which)
         out[key] = np.array(hashlib.sha256(v).hexdigest()) if digest else v

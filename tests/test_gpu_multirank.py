@@ -70,6 +70,40 @@ def test_multirank_strict_order_reproduces_single_rank_reference_bits(golden, or
     assert np.array_equal(np.asarray(res[0]["hist"]).view(np.uint64), ref["hist"].view(np.uint64))
 
 
+@pytest.mark.parametrize("world,n,iters,every", [(4, 1023, 60, 0), (4, 1023, 60, 1), (4, 1023, 61, 2), (2, 1023, 60, 3), (8, 2047, 24, 5),
+                                                 (4, 2047, 41, 7)])
+def test_multirank_strict_published_walk_and_its_completion_by_turns(oracle, tmp_path, monkeypatch, world, n, iters, every):
+    # Strict order on several ranks, lean schedule: every rank publishes its plan's briefs and finishes the walk itself (two
+    # collectives per dot product).  Where a brief does not hold for the true accumulator the dot product is completed by
+    # the ranks walking in turn; the test hook declares every `every`-th dot product failed (1: all of them; 2: every g.g,
+    # whose second pass has already run; 3, 5, 7: both kinds, at seams of every parity), 0 leaves the real failures only.
+    # Either way: the single-rank bits, on every rank.
+    if every:
+        monkeypatch.setenv("CG_TEST_FAULT_EVERY", str(every))
+    res = run_ranks(world, ["gpu", n, iters, tmp_path, "lean", 0.0, "strict"], tmp_path)
+    ref = oracle.cg(n, iters)
+    assert all(float(r["q1"]).hex() == float(ref["q1"]).hex() for r in res)
+    for k in ("u", "g", "d"):
+        assert np.array_equal(stack(res, k).view(np.uint64), ref[k].view(np.uint64)), k
+    assert np.array_equal(np.asarray(res[0]["hist"]).view(np.uint64), ref["hist"].view(np.uint64))
+    faults = {int(r["faults"]) for r in res}
+    assert len(faults) == 1                                        # every rank saw the same ones
+    if every:
+        # (a failed d.q has the whole iteration redone by turns, its g.g included; the leading iteration of a solve call walks
+        #  in turn anyway: at least every `every`-th of the remaining iterations must have gone that way)
+        assert faults.pop() >= max(1, (iters - 2) // every - 1)
+
+
+def test_multirank_strict_ranks_walking_in_turn_still_available(oracle, tmp_path, monkeypatch):
+    monkeypatch.setenv("CG_TEST_STRICT_CHAIN", "0")
+    n, iters = 1023, 40
+    res = run_ranks(4, ["gpu", n, iters, tmp_path, "lean", 0.0, "strict"], tmp_path)
+    ref = oracle.cg(n, iters)
+    assert all(float(r["q1"]).hex() == float(ref["q1"]).hex() for r in res)
+    assert np.array_equal(stack(res, "u").view(np.uint64), ref["u"].view(np.uint64))
+    assert all(int(r["faults"]) == 0 for r in res)
+
+
 @pytest.mark.parametrize("switch", ["classic>lean", "classic>fused", "classic>fused_noq", "lean>classic", "fused>lean"])
 def test_multirank_schedule_switch_between_two_solves_keeps_the_bits(oracle, tmp_path, switch):
     # The classic schedule exchanges d's boundary rows at the start of an iteration and changes d afterwards, so

@@ -22,6 +22,7 @@ s = cg.CGSolver(n, row0=rows, rows=rows, rank=1, nranks=P)
 k = [s.time_kernel(w, reps=50)[0] for w in (0, 1, 2)]
 kern = k[0] + (k[1] + k[2]) / 2
 print(f"kernels only: pass1 {k[0]*1e3:.1f} us, pass2 {k[1]*1e3:.1f} us, pass2+u {k[2]*1e3:.1f} us -> {kern*1e3:.1f} us per iteration", flush=True)
+per_fast = {}
 for label, graph, overlap in (("eager, exchange in line", 0, False), ("eager, exchange overlapped", 0, True),
                               ("hipGraph of 10, exchange in line", 10, False), ("hipGraph of 10, exchange overlapped", 10, True)):
     t = cg.CGSolver(n, row0=rows, rows=rows, rank=1, nranks=P)
@@ -30,6 +31,35 @@ for label, graph, overlap in (("eager, exchange in line", 0, False), ("eager, ex
     t.solve(21)                                            # warm-up: RCCL's first calls, graph capture
     r = t.solve(iters)
     per = 1e3 * r.seconds / max(r.iters, 1)               # ms, like the kernel times
+    per_fast[(graph, overlap)] = per
     print(f"{label:38s}: {per*1e3:8.1f} us per iteration  (+{(per - kern)*1e3:6.1f} us over the kernels, "
           f"{100 * kern / per:5.1f} % of the time is kernels)", flush=True)
     t.close()
+# The reference's summation order on several ranks: the accumulator of each dot product has to pass through the ranks' row
+# blocks.  Its cost depends on the data (binade crossings, hypotheses), so this part runs a WHOLE grid of about a rank's
+# share of points (n2 + 1 = 6144: 1.1 x the 2048 x 16384 block) on a single-rank context that issues the multi-rank
+# traffic to itself (CG_OPT_COMM_REHEARSAL = P): real numbers, real crossings.  "published": one all-gather of the
+# approximate totals, one of the plans' briefs, every rank finishes the walk; "in turn": one all-gather per rank and dot
+# product.  RCCL calls per iteration: halo 1 + dot products 2 x 2 (published) or 2 x (P + 1) (in turn); fast order 1 + 2.
+n2 = 6143
+rate = {}
+for label, red, reh, chain, graph in (("fast order, no traffic", cg.REDUCE_FAST, 0, 1, 10), ("fast order, rehearsed", cg.REDUCE_FAST, P, 1, 10),
+                                      ("strict, no traffic", cg.REDUCE_STRICT, 0, 1, 10),
+                                      ("strict, published briefs, hipGraph", cg.REDUCE_STRICT, P, 1, 10),
+                                      ("strict, published briefs, eager", cg.REDUCE_STRICT, P, 1, 0),
+                                      ("strict, ranks in turn, hipGraph", cg.REDUCE_STRICT, P, 0, 10)):
+    t = cg.CGSolver(n2)
+    if reh:
+        t.comm_init(cg.CGSolver.comm_unique_id())
+    t.configure(reduce=red, graph_iters=graph, overlap=False, comm_rehearsal=reh)
+    t.set_option(cg.lib.OPT_STRICT_CHAIN, chain)
+    t.init_problem()
+    t.solve(41)
+    r = t.solve(iters)
+    per = 1e6 * r.seconds / max(r.iters, 1)
+    rate[label] = per
+    calls = 0 if not reh else (3 if red == cg.REDUCE_FAST else 1 + 2 * (2 if chain else P + 1))
+    print(f"{n2 + 1}^2 {label:36s}: {per:8.1f} us per iteration, RCCL calls per iteration: {calls}, q1={float(r.q1).hex()}", flush=True)
+    t.close()
+print(f"strict (published briefs) / fast order, both with the traffic of {P} ranks: "
+      f"{rate['strict, published briefs, hipGraph'] / rate['fast order, rehearsed']:.2f}", flush=True)
