@@ -67,6 +67,18 @@ constexpr int kNoExp = INT_MIN;       // no usable guess
 
 typedef double xv2 __attribute__((ext_vector_type(2)));
 
+// The scalar step of the solver to run right behind a walk, in the same kernel (sc == nullptr: none): what k_finish would do
+// one launch later.  partials2 / count2: q.q partial sums to add up on the way (any order: prediction input), null or < 0 as there.
+struct FinishArgs {
+    Scalars *sc = nullptr;
+    int what = 0;
+    double rtol = 0.0;
+    double *hist = nullptr;
+    long hist_cap = 0;
+    const double *partials2 = nullptr;
+    long count2 = 0;
+};
+
 struct Summary {
     double D;         // sum of the rounded addends, in ulps of the hypothesised binade
     double mn, mx;    // extremes of the running value of D (the empty prefix, 0, included)
@@ -1207,7 +1219,7 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
                                                 const double *start_dev, double *result, long *stats,
                                                 const int *__restrict__ plist, const int *__restrict__ pexp,
                                                 const int *__restrict__ pn, const double *__restrict__ dump,
-                                                const int *skip = nullptr)
+                                                const int *skip = nullptr, const FinishArgs fin = FinishArgs())
 {
     if (skip != nullptr && *skip) return;               // a stopped or faulted solve: the workspace stays as it is
     __shared__ __attribute__((aligned(16))) double T[Src::kLds];
@@ -1287,8 +1299,15 @@ __global__ __launch_bounds__(64) void k_xs_walk(const Src src_in, long count,
             pos = end + 1;
         }
     }
+    double s2 = 0.0;
+    if (fin.sc != nullptr && fin.partials2 != nullptr) {
+        for (long k = lane; k < fin.count2; k += 64) s2 += fin.partials2[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+    }
     if (lane == 0) {
         *result = s;
+        if (fin.sc != nullptr) finish_scalars(fin.sc, fin.what, s, s2, fin.partials2 != nullptr, fin.count2, fin.rtol, fin.hist, fin.hist_cap);
         if (stats != nullptr) {
             stats[0] = n_groups; stats[1] = n_chunks; stats[2] = tally[0]; stats[3] = tally[1]; stats[4] = n_planned;
             stats[5] = n_general;
@@ -1340,7 +1359,7 @@ __global__ __launch_bounds__(64) void k_xs_pack(const int *__restrict__ pn, cons
 // quiet: a timing rehearsal with one rank standing in for all -- the other slots hold nothing, nothing is raised.
 // fault_every > 0 (test hook): declare every fault_every-th dot product failed, counted over the solve's iterations.
 __global__ __launch_bounds__(64) void k_xs_walk_remote(const double *__restrict__ slots, int nranks, int quiet, Scalars *sc, int phase,
-                                                       long fault_every, double *result, double *qq_out)
+                                                       long fault_every, double *result, double *qq_out, const FinishArgs fin)
 {
     if (sc->done) return;
     double s = slots[0], qq = slots[2];
@@ -1363,6 +1382,8 @@ __global__ __launch_bounds__(64) void k_xs_walk_remote(const double *__restrict_
     if (ok || quiet) {
         *result = s;
         *qq_out = qq;
+        // the solver's scalar step right here (q.q of the whole grid rides on the d.q walk)
+        if (fin.sc != nullptr) finish_scalars(fin.sc, fin.what, s, qq, phase == 0, 1, fin.rtol, fin.hist, fin.hist_cap);
     } else {
         sc->fault = 1 + phase;
         sc->done = 2;
@@ -1594,18 +1615,18 @@ inline void enqueue_summaries(hipStream_t s, const Workspace &ws, const Arrays &
 
 template <class Src>
 inline void enqueue_walk(hipStream_t s, const Workspace &ws, const Src &src, long count, double start, const double *start_dev,
-                         double *result, long *stats)
+                         double *result, long *stats, const FinishArgs &fin = FinishArgs())
 {
     if (count <= 0) {
         hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, 0L, ws.chunks, 0L, ws.groups, 0L,
                            start, start_dev, result, (long *)nullptr, (const int *)nullptr, (const int *)nullptr,
-                           (const int *)nullptr, (const double *)nullptr, ws.skip);
+                           (const int *)nullptr, (const double *)nullptr, ws.skip, fin);
         return;
     }
     const long nc = Workspace::chunks_for(count);
     const long ng = (nc + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(k_xs_walk<Src>, dim3(1), dim3(64), 0, s, src, count, ws.chunks, nc, ws.groups, ng,
-                       start, start_dev, result, stats, ws.plist, ws.pexp, ws.pn, ws.dump, ws.skip);
+                       start, start_dev, result, stats, ws.plist, ws.pexp, ws.pn, ws.dump, ws.skip, fin);
 }
 
 inline void enqueue(hipStream_t s, const Workspace &ws, const double *v, const double *w, long count, double start,

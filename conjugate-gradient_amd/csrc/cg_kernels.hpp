@@ -1035,29 +1035,16 @@ __device__ __forceinline__ double sane_ratio(double r)
     return (r > 0x1p-200 && r < 0x1p200) ? r : 1.0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long count,
-                                                   const double *strict_src, int nsrc, Scalars *sc, int what,
-                                                   double rtol, double *hist, long hist_cap,
-                                                   const double *partials2 = nullptr, long count2 = 0)
+// The scalar step that follows a dot product (one thread): s = the dot product, s2 = q.q of the same pass where
+// have_s2 (prediction input only; count2 < 0 without it: several ranks walking in turn fall back on the last beta).
+__device__ __forceinline__ void finish_scalars(Scalars *sc, int what, double s, double s2, bool have_s2, long count2, double rtol,
+                                               double *hist, long hist_cap)
 {
-    if ((what < 2 || what == 4) && sc->done) return;
-    __shared__ double wave_slots[kWaves];
-    double s = sum_partials(partials, (strict_src == nullptr && what != 5) ? count : 0, wave_slots);
-    double s2 = 0.0;
-    if (partials2 != nullptr) {                        // q.q partials of the speculative strict pass
-        __syncthreads();
-        s2 = sum_partials(partials2, count2, wave_slots);
-    }
-    if (threadIdx.x != 0) return;
-    if (strict_src != nullptr) {
-        s = strict_src[0];
-        for (int r = 1; r < nsrc; ++r) s += strict_src[r];
-    }
     if (what == 0) {
         sc->dq = s;
         sc->tau = sc->q0 / s;
         sc->tau_ring[sc->iter & 7] = sc->tau;
-        if (partials2 != nullptr) {
+        if (have_s2) {
             sc->qq = s2;
             sc->rho[1] = sane_ratio((sc->tau * sc->tau * s2 - sc->q0) / sc->q0);
         } else if (count2 < 0) {
@@ -1098,6 +1085,27 @@ __global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long 
     } else {
         sc->dot = s;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_finish(const double *partials, long count,
+                                                   const double *strict_src, int nsrc, Scalars *sc, int what,
+                                                   double rtol, double *hist, long hist_cap,
+                                                   const double *partials2 = nullptr, long count2 = 0)
+{
+    if ((what < 2 || what == 4) && sc->done) return;
+    __shared__ double wave_slots[kWaves];
+    double s = sum_partials(partials, (strict_src == nullptr && what != 5) ? count : 0, wave_slots);
+    double s2 = 0.0;
+    if (partials2 != nullptr) {                        // q.q partials of the speculative strict pass
+        __syncthreads();
+        s2 = sum_partials(partials2, count2, wave_slots);
+    }
+    if (threadIdx.x != 0) return;
+    if (strict_src != nullptr) {
+        s = strict_src[0];
+        for (int r = 1; r < nsrc; ++r) s += strict_src[r];
+    }
+    finish_scalars(sc, what, s, s2, partials2 != nullptr, count2, rtol, hist, hist_cap);
 }
 
 // The same fixed-order sum, written to a caller-supplied device location.

@@ -517,7 +517,7 @@ int strict_rank_chain(cg_ctx *c, FA approx, FS summaries, FW walk, const double 
 // raises Scalars::done = 2 instead, and cg_solve completes the dot product with strict_chain_walks.
 template <class FA, class FS, class FW>
 int strict_chain_published(cg_ctx *c, FA approx, FS summaries, FW walk, int phase, const double *partials2, long count2,
-                           const double **result_at)
+                           const cg::exact::FinishArgs &fin, const double **result_at)
 {
     hipStream_t s = c->stream;
     const bool self = c->comm->self_only();             // timing rehearsal: this rank stands in for all
@@ -536,7 +536,7 @@ int strict_chain_published(cg_ctx *c, FA approx, FS summaries, FW walk, int phas
     HIPCHK(hipGetLastError());
     CGCHK(comm_rc(c, c->comm->allgather_block(s, cg::exact::kPayload)));
     hipLaunchKernelGGL(cg::exact::k_xs_walk_remote, dim3(1), dim3(64), 0, s, self ? slots + (long)c->rank * cg::exact::kPayload : slots,
-                       self ? 1 : c->nranks, self ? 1 : 0, c->sc, phase, c->fault_every, c->strict_slot, c->strict_slot + 1);
+                       self ? 1 : c->nranks, self ? 1 : 0, c->sc, phase, c->fault_every, c->strict_slot, c->strict_slot + 1, fin);
     HIPCHK(hipGetLastError());
     *result_at = c->strict_slot;
     return CG_OK;
@@ -720,18 +720,26 @@ int enqueue_lean_iteration(cg_ctx *c)
         auto f_summ = [&](const double *seed, int nseed) {
             cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 0, false, &c->sc->rho[0], 0.0, seed, nseed);
         };
+        // the scalar step (tau, the growth prediction for g.g) rides in the kernel that completes the dot product: the walk of
+        // a single rank, the published walk of several; the ranks walking in turn (and the self-check) keep k_finish
+        const bool published = c->multi() && c->strict_chain && !c->strict_safe && !c->strict_audit;
+        const bool fused_finish = !c->strict_audit && (published || !c->multi());
+        cg::exact::FinishArgs fin;
+        fin.sc = c->sc; fin.what = 0; fin.hist = c->hist; fin.hist_cap = c->hist_cap;
+        fin.partials2 = a.partials2; fin.count2 = tq.ntiles;
         auto f_walk = [&](const double *start_dev, double *result) {
-            cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats);
+            cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats,
+                                    (fused_finish && !published) ? fin : cg::exact::FinishArgs());
             if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
         };
-        const bool published = c->multi() && c->strict_chain && !c->strict_safe && !c->strict_audit;
-        if (published) CGCHK(strict_chain_published(c, f_approx, f_summ, f_walk, 0, a.partials2, tq.ntiles, &at));
+        if (published) CGCHK(strict_chain_published(c, f_approx, f_summ, f_walk, 0, a.partials2, tq.ntiles, fin, &at));
         else CGCHK(strict_rank_chain(c, f_approx, f_summ, f_walk, &at));
-        // the growth prediction for g.g needs q.q of the whole grid: this rank's partial sums, or (published walk) the
-        // ranks' sums added up on the way; the ranks walking in turn fall back on the last beta
-        const double *qq = published ? at + 1 : (c->nranks == 1 ? (const double *)a.partials2 : (const double *)nullptr);
-        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_dq, tq.ntiles, at, 1, c->sc, 0, 0.0,
-                           c->hist, c->hist_cap, qq, published ? 1L : (c->nranks == 1 ? tq.ntiles : -1L));
+        // (the growth prediction for g.g needs q.q of the whole grid: this rank's partial sums, or, published walk, the
+        //  ranks' sums added up on the way; the ranks walking in turn fall back on the last beta)
+        if (!fused_finish)
+            hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_dq, tq.ntiles, at, 1, c->sc, 0, 0.0,
+                               c->hist, c->hist_cap, c->nranks == 1 ? (const double *)a.partials2 : (const double *)nullptr,
+                               c->nranks == 1 ? tq.ntiles : -1L);
     } else {
         if (strict) {
             a.q = c->q; a.store_products = 1;
@@ -785,16 +793,20 @@ int enqueue_lean_iteration(cg_ctx *c)
         auto f_summ = [&](const double *seed, int nseed) {
             cg::exact::spec_summaries(s, c->xs, src, c->G, c->rows, 1, true, &c->sc->rho[1], 0.0, seed, nseed);
         };
+        const bool published = c->multi() && c->strict_chain && !c->strict_safe && !c->strict_audit;
+        const bool fused_finish = !c->strict_audit && (published || !c->multi());
+        cg::exact::FinishArgs fin;
+        fin.sc = c->sc; fin.what = with_u ? 1 : 4; fin.hist = c->hist; fin.hist_cap = c->hist_cap;
         auto f_walk = [&](const double *start_dev, double *result) {
-            cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats + 8);
+            cg::exact::enqueue_walk(s, c->xs, src, c->count, 0.0, start_dev, result, c->xs.stats + 8,
+                                    (fused_finish && !published) ? fin : cg::exact::FinishArgs());
             if (c->strict_audit) cg::exact::enqueue_audit(s, c->xs, src, c->count, 0.0, start_dev, result);
         };
-        if (c->multi() && c->strict_chain && !c->strict_safe && !c->strict_audit)
-            CGCHK(strict_chain_published(c, f_approx, f_summ, f_walk, 1, (const double *)nullptr, 0L, &at));
-        else
-            CGCHK(strict_rank_chain(c, f_approx, f_summ, f_walk, &at));
-        hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_gg, n_gg, at, 1, c->sc, with_u ? 1 : 4, 0.0,
-                           c->hist, c->hist_cap);
+        if (published) CGCHK(strict_chain_published(c, f_approx, f_summ, f_walk, 1, (const double *)nullptr, 0L, fin, &at));
+        else CGCHK(strict_rank_chain(c, f_approx, f_summ, f_walk, &at));
+        if (!fused_finish)
+            hipLaunchKernelGGL(cg::k_finish, dim3(1), dim3(kBlock), 0, s, p_gg, n_gg, at, 1, c->sc, with_u ? 1 : 4, 0.0,
+                               c->hist, c->hist_cap);
     } else {
         CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
     }
