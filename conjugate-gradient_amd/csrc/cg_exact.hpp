@@ -633,6 +633,25 @@ __global__ __launch_bounds__(256) void k_sp_select(const UnitRec *__restrict__ r
     chunks[c] = cs;
 }
 
+// First hypotheses for the kernels above, from a dot product that was evaluated the other way (products stored, span
+// sums of kSub by rows in `sub`, approx / goff as k_xs_from_sub and k_xs_gscan left them): the approximate prefix sum
+// at every unit's start, where k_sp_select would have put it.  One thread per unit, consecutive threads down a column.
+__global__ __launch_bounds__(256) void k_sp_seed(const double *__restrict__ sub, long G, long rows,
+                                                 const double *__restrict__ approx, const double *__restrict__ goff,
+                                                 double *__restrict__ hyp, const int *skip = nullptr)
+{
+    if (skip != nullptr && *skip) return;
+    constexpr int kUnits = kChunk / kUnit, kSpans = kUnit / kSub;
+    const long ucols = G / kUnit, ccols = G / kChunk;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ucols * rows) return;
+    const long j = idx / rows, m = idx - j * rows;
+    const long cc = j / kUnits, c = m * ccols + cc;
+    double guess = goff[c >> 6] + approx[c];
+    for (long k = cc * kUnits * kSpans; k < j * kSpans; ++k) guess += sub[k * rows + m];    // the chunk's units before this one
+    hyp[idx] = guess;
+}
+
 // Chunks on the repair list: their products are recomputed from the source and summarised under the guess at
 // the chunk's start, exactly as k_xs_chunk does for stored products.  Persistent wavefronts over the list.
 template <class Src>
@@ -1652,6 +1671,14 @@ inline void spec_approx(hipStream_t s, const Workspace &ws, long G, long rows, d
     hipLaunchKernelGGL(k_xs_from_sub, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (const double *)ws.rec, count / kUnit,
                        nc, G, rows, ws.approx, ws.goff, (int)kUnit, 4, ws.skip);
     if (total_out) hipLaunchKernelGGL(k_xs_total, dim3(1), dim3(1024), 0, s, ws.goff, ng, total_out, ws.skip);
+}
+
+// Seeds ws.hyp[which] from the dot product whose approximate sums (span sums by rows) are in the workspace.
+inline void spec_seed(hipStream_t s, const Workspace &ws, long G, long rows, int which)
+{
+    const long units = (G / kUnit) * rows;
+    hipLaunchKernelGGL(k_sp_seed, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, (const double *)ws.sub, G, rows,
+                       (const double *)ws.approx, (const double *)ws.goff, ws.hyp[which], ws.skip);
 }
 
 template <class Src>

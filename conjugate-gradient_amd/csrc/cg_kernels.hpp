@@ -581,8 +581,11 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     const unsigned in_bytes = (unsigned)(r1 - r0 + 2) * (unsigned)rowbytes, own_bytes = (unsigned)(r1 - r0) * (unsigned)rowbytes;
     const __amdgpu_buffer_rsrc_t td = row_rsrc_nn(a.d_in + (long)(r0 - 1) * G, CONTIG ? (int)in_bytes : 0);
     const __amdgpu_buffer_rsrc_t tg = row_rsrc_nn((FUSE_D ? a.g : a.d_in) + (long)(r0 - 1) * G, (CONTIG && FUSE_D) ? (int)in_bytes : 0);
+    // MODE 2 without u (a.u == nullptr: the update is left to the next iteration's paired one): descriptors of no
+    // bytes, so the loads deliver zeros and the stores are dropped without touching memory
+    const bool has_u = (MODE == 5) || (MODE == 2 && a.u != nullptr);
     const __amdgpu_buffer_rsrc_t tu = row_rsrc_nn(((MODE == 2 || MODE == 5) ? a.u : a.d_in) + (long)r0 * G,
-                                                  (CONTIG && (MODE == 2 || MODE == 5)) ? (int)own_bytes : 0);
+                                                  (CONTIG && has_u) ? (int)own_bytes : 0);
     const __amdgpu_buffer_rsrc_t tgw = row_rsrc_nn(((MODE == 2) ? a.gw : a.d_in) + (long)r0 * G, (CONTIG && MODE == 2) ? (int)own_bytes : 0);
     auto umin = [](unsigned x, unsigned y) { return x < y ? x : y; };
     auto load_row = [&](int r, RawRow<VEC> &raw) {
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
             if (NH > 0) raw.hyp = buf_load1(hyp_rsrc, (r >= 0 && r < nrows) ? r * 8 : kOOB);
             if (MODE == 2 || MODE == 5) {
                 const bool own = (r >= r0) && (r < r1);
-                BufIO<VEC>::load(row_rsrc_nn(a.u + (long)r * G, own ? rowbytes : 0), off_main, raw.u);
+                BufIO<VEC>::load(row_rsrc_nn(a.u + (long)r * G, (own && has_u) ? rowbytes : 0), off_main, raw.u);
                 if (MODE == 2) BufIO<VEC>::load(row_rsrc_nn(a.gw + (long)r * G, own ? rowbytes : 0), off_main, raw.g);
             }
         }
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                     pg[v] = mid_g[v] + tau * qv[v];
                     acc += pg[v] * pg[v];             // masked rows/lanes hold g = 0
                 }
-                BufIO<VEC>::store(row_rsrc_nn(a.u +(long)m * G, row_own ? rowbytes : 0), off_main, pu);
+                BufIO<VEC>::store(row_rsrc_nn(a.u +(long)m * G, (row_own && has_u) ? rowbytes : 0), off_main, pu);
                 BufIO<VEC>::store(row_rsrc_nn(a.gw +(long)m * G, row_own ? rowbytes : 0), off_main, pg);
                 if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
                     double span = pg[0] * pg[0];
@@ -1051,8 +1054,9 @@ __device__ __forceinline__ void finish_scalars(Scalars *sc, int what, double s, 
             sc->rho[1] = sane_ratio(sc->beta);          // several ranks: q.q is not known globally; the last ratio will do
         }
     } else if (what == 1 || what == 4) {
-        // next iteration's d.q, predicted from the new q0 and the step length of the iteration before this one
-        sc->rho[0] = (sc->iter >= 1) ? sane_ratio(s / sc->tau_ring[(sc->iter - 1) & 7] / sc->dq) : 1.0;
+        // next iteration's d.q, predicted from the new q0 and the step length of the iteration before this one (the
+        // step lengths of CG alternate; the very first iteration has only its own)
+        sc->rho[0] = sane_ratio(s / sc->tau_ring[(sc->iter >= 1 ? sc->iter - 1 : sc->iter) & 7] / sc->dq);
         sc->q1 = s;
         sc->beta = s / sc->q0;
         sc->q0 = s;

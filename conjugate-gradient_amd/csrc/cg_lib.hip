@@ -271,6 +271,11 @@ struct cg_ctx {
     int resum_q0 = 0;                     // a solve that continues the previous one sums q0 = g.g again (cg.c:55) instead of taking it over
     int strict_chain = 1;                 // several ranks, strict order, lean schedule: 1 = the ranks publish their plans' briefs and every
                                           // rank finishes the walk (two collectives per dot product); 0 = the ranks walk in turn
+    int time_dir = -1;                    // cg_time_kernel, lean passes: -1 = the buffers swap roles from launch to launch (as in a solve),
+                                          // 0 / 1 = every launch reads buffer pair 0 / 1 (choose_placement times the two directions apart)
+    int time_warm = 2;                    // ... untimed launches first
+    double pass_ms[3][2] = {{0, 0}, {0, 0}, {0, 0}};   // measured by choose_placement: lean pass (d.q, g', g' + u) x direction, 0 = not measured
+    bool lead_defers_u = false;           // lean schedule: the leading iteration of the present solve leaves its u update to the first pair
     bool strict_safe = false;             // the iteration being enqueued completes a faulted dot product: ranks walk in turn
     long fault_every = 0;                 // test hook: the published walk declares every n-th dot product failed
     long strict_faults = 0;               // dot products completed by the ranks walking in turn after the published walk gave up
@@ -863,6 +868,9 @@ int enqueue_iteration(cg_ctx *c, bool first)
         if (!first) return enqueue_lean_iteration(c);
         sched = CG_SCHED_FUSED_NOQ;       // d is materialised: stencil pass + in-place update pass, as there
     }
+    // The lean schedule applies u's updates in pairs; cg_solve may ask the leading iteration to leave its own to the
+    // first pair (then a solve of an even number of iterations ends with none left over).
+    const bool defer_u = lean && first && c->lead_defers_u;
     const TileGeom t = ctx_geom(c), tq = dq_geom(c, t);
     const long nvec = c->count / t.vec;
     const int fb = flat_blocks(nvec, c->flat_blocks_opt);
@@ -947,6 +955,11 @@ int enqueue_iteration(cg_ctx *c, bool first)
     HIPCHK(hipGetLastError());
     if (products) CGCHK(enqueue_dot_finish(c, c->q, nullptr, p_dq, tq.ntiles, 0, 0.0, a.sub ? 2 : 0));
     else CGCHK(enqueue_dot_finish(c, c->d[c->dcur], c->q, p_dq, tq.ntiles, 0, 0.0, a.sub ? 2 : 0));
+    // The lean iterations that follow summarise their products under hypotheses taken from the iteration before;
+    // this one hands them its approximate prefix sums (without them the first of them would summarise every chunk twice).
+    const bool seed = lean && sub != nullptr && strict_speculative(c, t) && c->strict_blocks <= 1 &&
+                      use_parallel_strict(c->strict_impl, c->count);
+    if (seed) { cg::exact::spec_seed(s, c->xs, c->G, c->rows, 0); HIPCHK(hipGetLastError()); }
 
     // ---- u += tau d ; g += tau q (+ g.g)
     double *gg_sub = nullptr;
@@ -955,7 +968,7 @@ int enqueue_iteration(cg_ctx *c, bool first)
         b.d_in = c->d[c->dcur];
         b.d_top = c->has_top() ? c->halo_d[c->dcur][0] : nullptr;
         b.d_bot = c->has_bot() ? c->halo_d[c->dcur][1] : nullptr;
-        b.u = c->u; b.gw = c->g; b.partials = p_gg;
+        b.u = defer_u ? nullptr : c->u; b.gw = c->g; b.partials = p_gg;
         b.sub = gg_sub = sub;
         launch_stencil<2, false>(t, b, s);
     } else {
@@ -969,8 +982,10 @@ int enqueue_iteration(cg_ctx *c, bool first)
     // The lean schedule's iterations expect g's halo rows in place when they begin (each one sends its
     // own new rows off before it ends): the iteration that leads into them does the same.
     if (lean && c->multi()) CGCHK(exchange_g_rows(c, s, c->g));
-    CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, 1, 0.0,
+    CGCHK(enqueue_dot_finish(c, c->g, c->g, p_gg, npart_gg, defer_u ? 4 : 1, 0.0,
                              gg_sub == nullptr ? 0 : (sched == CG_SCHED_FUSED_NOQ ? 2 : 1)));   // tiled kernel: by rows; flat: linear
+    if (lean) c->lean_pending = defer_u ? 1 : 0;
+    if (seed) { cg::exact::spec_seed(s, c->xs, c->G, c->rows, 1); HIPCHK(hipGetLastError()); }
 
     // ---- d = beta d - g: now (classic) or inside the next stencil kernel (fused)
     if (sched == CG_SCHED_CLASSIC) {
@@ -1515,14 +1530,33 @@ static int choose_placement(cg_ctx *c)
         return free_b >= 8 * c->padded_bytes && free_b - 6 * c->padded_bytes >= free_start / 2;
     };
     if (!room()) return CG_OK;
-    auto cost = [&](double *ms, int *pf_u) -> int {     // two iterations of the lean schedule; the six-stream pass with
-        double t[4] = {0.0, 0.0, 0.0, 0.0};             // one and with two rows in flight (which is better depends on the set)
-        for (int which = 0; which < 4; ++which) {
-            c->pf_update_u = (which == 3) ? 1 : 2;
-            CGCHK(cg_time_kernel(c, which < 3 ? which : 2, 3, &t[which], nullptr));
+    // Two iterations of the lean schedule.  Every pass is timed in both directions (reading buffer pair 0 and writing
+    // pair 1, and the other way round: the same kernel can differ by 10 % between them), the six-stream pass with one
+    // and with two rows in flight (which is better depends on the set).  A solve runs the four-stream pass in one
+    // direction and the six-stream pass in the other throughout, and cg_solve picks the cheaper assignment.
+    struct Cost { double ms; int pf; double pass[3][2]; };
+    auto cost = [&](Cost *out) -> int {
+        double t[4][2];
+        c->time_warm = 1;
+        int rc = CG_OK;
+        for (int which = 0; which < 4 && rc == CG_OK; ++which)
+            for (int dir = 0; dir < 2 && rc == CG_OK; ++dir) {
+                c->pf_update_u = (which == 3) ? 1 : 2;
+                c->time_dir = dir;
+                rc = cg_time_kernel(c, which < 3 ? which : 2, 2, &t[which][dir], nullptr);
+            }
+        c->time_dir = -1; c->time_warm = 2;
+        if (rc != CG_OK) return rc;
+        out->ms = 1e30;
+        for (int pf = 1; pf <= 2; ++pf) {
+            const double *six = t[pf == 1 ? 3 : 2];
+            const double best6 = (t[1][0] + six[1] < t[1][1] + six[0]) ? t[1][0] + six[1] : t[1][1] + six[0];
+            const double ms = t[0][0] + t[0][1] + best6;
+            if (ms < out->ms) {
+                out->ms = ms; out->pf = pf;
+                for (int dir = 0; dir < 2; ++dir) { out->pass[0][dir] = t[0][dir]; out->pass[1][dir] = t[1][dir]; out->pass[2][dir] = six[dir]; }
+            }
         }
-        *pf_u = (t[3] < t[2]) ? 1 : 2;
-        *ms = 2.0 * t[0] + t[1] + 0.5 * (t[2] + t[3]);   // both forms count: the strict order keeps one row in flight there
         return CG_OK;
     };
     // diagnostic: CG_PLACEMENT_KEEP=worst keeps the slowest set instead (to put a slow placement under the profiler)
@@ -1531,9 +1565,8 @@ static int choose_placement(cg_ctx *c)
     VectorSet best;
     best.u = c->u_alloc; best.q = c->q_alloc; best.g[0] = c->g_alloc[0]; best.g[1] = c->g_alloc[1];
     best.d[0] = c->d_alloc[0]; best.d[1] = c->d_alloc[1];
-    double best_ms = 0.0;
-    int best_pf = 0;
-    int rc = cost(&best_ms, &best_pf);
+    Cost best_cost;
+    int rc = cost(&best_cost);
     VectorSet rejected[8];
     int nrej = 0;
     for (int k = 1; rc == CG_OK && k < draws && k < 8; ++k) {
@@ -1541,15 +1574,40 @@ static int choose_placement(cg_ctx *c)
         VectorSet v;
         if (!alloc_vectors(v, c->padded_bytes)) break;
         adopt_vectors(c, v);
-        double ms = 0.0;
-        int pf = 0;
-        rc = cost(&ms, &pf);
-        if (getenv("CG_DEBUG_PLACEMENT")) fprintf(stderr, "placement draw %d: %.3f ms per two iterations (kept so far %.3f)\n", k, ms, best_ms);
-        if (rc == CG_OK && (keep_worst ? ms > best_ms : ms < 0.995 * best_ms)) { rejected[nrej++] = best; best = v; best_ms = ms; best_pf = pf; }
+        Cost now;
+        rc = cost(&now);
+        if (getenv("CG_DEBUG_PLACEMENT")) fprintf(stderr, "placement draw %d: %.3f ms per two iterations (kept so far %.3f)\n", k, now.ms, best_cost.ms);
+        if (rc == CG_OK && (keep_worst ? now.ms > best_cost.ms : now.ms < 0.995 * best_cost.ms)) { rejected[nrej++] = best; best = v; best_cost = now; }
         else rejected[nrej++] = v;
     }
+    // Second stage: what makes a set slow is how the streams of a pass meet in the L2's sets, a matter of the vectors'
+    // physical frames relative to one another -- so single vectors of the kept set are traded against the same vector
+    // of every rejected set, one role after the other, and a trade stays where the passes get faster.
+    int refine = 1;
+    if (const char *e = getenv("CG_PLACEMENT_REFINE")) refine = atoi(e);
+    auto role_of = [](VectorSet &v, int role) -> double *& {
+        return role == 0 ? v.d[0] : role == 1 ? v.d[1] : role == 2 ? v.g[0] : role == 3 ? v.g[1] : v.u;
+    };
+    for (int round = 0; rc == CG_OK && !keep_worst && round < refine && nrej > 0; ++round) {
+        bool traded = false;
+        for (int role = 0; rc == CG_OK && role < 5; ++role)
+            for (int k = 0; rc == CG_OK && k < nrej; ++k) {
+                std::swap(role_of(best, role), role_of(rejected[k], role));
+                adopt_vectors(c, best);
+                Cost now;
+                rc = cost(&now);
+                if (getenv("CG_DEBUG_PLACEMENT")) fprintf(stderr, "placement trade: role %d with set %d: %.3f ms (kept so far %.3f)\n", role, k, now.ms, best_cost.ms);
+                if (rc == CG_OK && now.ms < 0.995 * best_cost.ms) { best_cost = now; traded = true; }
+                else std::swap(role_of(best, role), role_of(rejected[k], role));
+            }
+        if (!traded) break;
+    }
     adopt_vectors(c, best);
-    c->pf_update_u = (rc == CG_OK) ? best_pf : 0;
+    c->pf_update_u = (rc == CG_OK) ? best_cost.pf : 0;
+    if (rc == CG_OK && !keep_worst) memcpy(c->pass_ms, best_cost.pass, sizeof c->pass_ms);
+    if (getenv("CG_DEBUG_PLACEMENT") && rc == CG_OK)
+        fprintf(stderr, "placement kept: d.q %.3f / %.3f  g' %.3f / %.3f  g'+u %.3f / %.3f ms (direction 0 / 1), %d row(s) in flight\n", best_cost.pass[0][0],
+                best_cost.pass[0][1], best_cost.pass[1][0], best_cost.pass[1][1], best_cost.pass[2][0], best_cost.pass[2][1], best_cost.pf);
     for (int k = 0; k < nrej; ++k) rejected[k].release();
     // back to the state of a fresh context
     double *all[6] = {best.u, best.q, best.g[0], best.g[1], best.d[0], best.d[1]};
@@ -1883,6 +1941,29 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     const bool cont = c->live;
     const bool first_form = (sched == CG_SCHED_CLASSIC) ? false : !c->pending_dupdate;   // iteration 0 has no d update to fold in
     const long lead = (first_form && max_iters > 0) ? 1 : 0;                             // iterations enqueued before the graph
+    // Lean schedule: every second iteration applies two u updates at once.  With an odd number of iterations behind
+    // the leading one, the leading one leaves its update to the first of them, so that the last iteration completes
+    // a pair and the solve ends with no update of u owed (a stop rule that fires early may still leave one).
+    c->lead_defers_u = false;
+    if (lead && sched == CG_SCHED_LEAN) {
+        // Cost of the n iterations behind the leading one either way, in units that only need to be consistent: the
+        // passes' measured times per direction where the context measured them (one rank, large grid: the four- and the
+        // six-stream pass keep one direction each for the whole solve), else their bytes per point.
+        const long n = max_iters - lead;
+        const bool measured = c->nranks == 1 && c->pass_ms[1][0] > 0.0;
+        const int d0 = c->dcur;                     // the direction of the first of them
+        const double m4[2] = {measured ? c->pass_ms[1][d0] : 32.0, measured ? c->pass_ms[1][d0 ^ 1] : 32.0};
+        const double m5[2] = {measured ? c->pass_ms[2][d0] : 48.0, measured ? c->pass_ms[2][d0 ^ 1] : 48.0};
+        const double per_byte = 0.5 * (m4[0] + m4[1]) / 32.0;
+        const double flush = 24.0 * per_byte, lead_u = 16.0 * per_byte;   // a u update on its own; u's share of the leading iteration
+        const double deferred = (double)((n + 1) / 2) * m5[0] + (double)(n / 2) * m4[1] + ((n > 0 && !(n & 1)) ? flush : 0.0) - lead_u;
+        const double at_once = (double)((n + 1) / 2) * m4[0] + (double)(n / 2) * m5[1] + ((n & 1) ? flush : 0.0);
+        c->lead_defers_u = n > 0 && deferred < at_once;
+    }
+    struct PendGuard {                      // the graph is chosen for the state the leading iteration will leave
+        cg_ctx *c; int saved;
+        ~PendGuard() { c->lean_pending = saved; }
+    };
 
     // Graph of the steady-state iteration body (set-up, outside the timed region), for the buffer roles
     // the context will be in after the leading iteration (which works in place and leaves no u update owed).
@@ -1892,6 +1973,8 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     if (c->multi() && !c->comm->stream_ordered()) glen = 0;
     GraphSlot *graph = nullptr;
     if (glen > 0 && max_iters - lead >= glen) {
+        PendGuard guard{c, c->lean_pending};
+        if (lead && sched == CG_SCHED_LEAN) c->lean_pending = c->lead_defers_u ? 1 : 0;
         graph = find_graph(c, sched);
         bool agree = c->multi() && graph == nullptr;
         if (!graph) {
@@ -2080,6 +2163,7 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     double per_point = 0.0;
     auto launch = [&]() {
         if (sched == CG_SCHED_LEAN) {
+            if (c->time_dir >= 0) { c->dcur = c->time_dir; c->set_gcur(c->time_dir); }
             StencilArgs a = base_args(c, which == 0 ? tq : t);
             const int out = c->dcur ^ 1;
             a.partials = c->partials; a.d_in = c->d[c->dcur]; a.g = c->g;
@@ -2139,7 +2223,7 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    launch(); launch();                                   // warm-up
+    for (int i = 0; i < c->time_warm; ++i) launch();      // warm-up
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) launch();

@@ -267,6 +267,25 @@ def test_speculative_summaries_give_the_bits_of_the_stored_products_path(cg, ora
     print(f"n={n}: {misses} of {(n + 1) * (n + 1) // 1024} chunks redone in the last dot product")
 
 
+def test_leading_iteration_hands_its_prefix_sums_to_the_first_speculating_iteration(cg, oracle):
+    # The iteration that starts a solve evaluates its dot products from stored products; the approximate prefix sums it
+    # forms on the way become the hypotheses of the iteration behind it, which would otherwise redo every chunk.
+    n = 2047
+    chunks = (n + 1) * (n + 1) // 1024
+    for iters in (2, 3):
+        s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_spec=True, graph_iters=0).init_problem()
+        s.solve(iters)
+        misses = s.get_option(cg.lib.OPT_STRICT_MISSES)
+        print(f"n={n}: {misses} of {chunks} chunks redone in the last dot product of iteration {iters}")
+        assert misses < chunks // 4
+        b = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, strict_spec=False).init_problem()
+        b.solve(iters)
+        assert np.array_equal(bits(s.history(iters)), bits(b.history(iters)))
+        for which in (cg.VEC_U, cg.VEC_G, cg.VEC_D):
+            assert np.array_equal(bits(s.vector(which)), bits(b.vector(which))), which
+        s.close(); b.close()
+
+
 def test_speculative_summaries_continue_across_solves_and_stop_rule(cg, oracle):
     n = 1023
     ref = oracle.cg(n, 120)
