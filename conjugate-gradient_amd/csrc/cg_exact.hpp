@@ -652,6 +652,41 @@ __global__ __launch_bounds__(256) void k_sp_seed(const double *__restrict__ sub,
     hyp[idx] = guess;
 }
 
+// What the hypotheses still lack after k_sp_seed is the growth of the total to the next iteration, and the scalar
+// recurrences cannot predict it behind the very first iteration (the step length changes by orders of magnitude there).
+// The SHAPE of the prefix sums hardly changes, though, so the ratio of the two iterations' sums over a band of rows
+// stands in for the ratio of the totals: k_band_sum adds up this iteration's span sums over rows [m0, m1) (one
+// workgroup), the next iteration evaluates the same rows ahead of its pass and divides (k_band_rho), and leaves its own
+// sum for the iteration behind it.
+__global__ __launch_bounds__(256) void k_band_sum(const double *__restrict__ sub, long G, long rows, long m0, long m1,
+                                                  double *__restrict__ out, const int *skip = nullptr)
+{
+    if (skip != nullptr && *skip) return;
+    __shared__ double wave_tot[4];
+    const long nspans = G / kSub, width = m1 - m0;
+    double acc = 0.0;
+    for (long k = threadIdx.x; k < nspans * width; k += 256) acc += sub[(k / width) * rows + m0 + k % width];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (wave_tot[0] + wave_tot[1]) + (wave_tot[2] + wave_tot[3]);
+}
+
+__global__ __launch_bounds__(64) void k_band_rho(const double *__restrict__ partials, long count, double *__restrict__ before,
+                                                 Scalars *sc, const int *skip = nullptr)
+{
+    if (skip != nullptr && *skip) return;
+    double acc = 0.0;
+    for (long k = threadIdx.x; k < count; k += 64) acc += partials[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (threadIdx.x == 0) {
+        sc->rho[0] = sane_ratio(acc / *before);
+        *before = acc;                                   // the next iteration's reference
+    }
+}
+
 // Chunks on the repair list: their products are recomputed from the source and summarised under the guess at
 // the chunk's start, exactly as k_xs_chunk does for stored products.  Persistent wavefronts over the list.
 template <class Src>

@@ -1055,8 +1055,8 @@ __device__ __forceinline__ void finish_scalars(Scalars *sc, int what, double s, 
         }
     } else if (what == 1 || what == 4) {
         // next iteration's d.q, predicted from the new q0 and the step length of the iteration before this one (the
-        // step lengths of CG alternate; the very first iteration has only its own)
-        sc->rho[0] = sane_ratio(s / sc->tau_ring[(sc->iter >= 1 ? sc->iter - 1 : sc->iter) & 7] / sc->dq);
+        // step lengths of CG alternate; the first two iterations use their own: the very first step is far off the rest)
+        sc->rho[0] = sane_ratio(s / sc->tau_ring[(sc->iter >= 2 ? sc->iter - 1 : sc->iter) & 7] / sc->dq);
         sc->q1 = s;
         sc->beta = s / sc->q0;
         sc->q0 = s;

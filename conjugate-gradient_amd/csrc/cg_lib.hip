@@ -275,6 +275,9 @@ struct cg_ctx {
                                           // 0 / 1 = every launch reads buffer pair 0 / 1 (choose_placement times the two directions apart)
     int time_warm = 2;                    // ... untimed launches first
     double pass_ms[3][2] = {{0, 0}, {0, 0}, {0, 0}};   // measured by choose_placement: lean pass (d.q, g', g' + u) x direction, 0 = not measured
+    int band_left = 0;                    // strict order, lean schedule: so many of the next iterations predict the growth of d.q from a band
+                                          // of rows (the band's last sum is in strict_slot[4]; cg_exact.hpp, k_band_sum)
+    long band_lo = 0, band_hi = 0;
     bool lead_defers_u = false;           // lean schedule: the leading iteration of the present solve leaves its u update to the first pair
     bool strict_safe = false;             // the iteration being enqueued completes a faulted dot product: ranks walk in turn
     long fault_every = 0;                 // test hook: the published walk declares every n-th dot product failed
@@ -662,6 +665,15 @@ int enqueue_uflush(cg_ctx *c, int pending, int newest_slot)
     return CG_OK;
 }
 
+// Strict order: the scalar recurrences predict the growth of d.q from one iteration to the next well enough for the
+// hypotheses of the span sums (cg_exact.hpp), but not behind the very first iteration of a problem (the first step length
+// is orders of magnitude off the rest): a wrong prediction has every chunk of the pass summarised twice, two milliseconds
+// at 16384^2.  So the iteration behind the first one measures the growth instead, on a band of 64 rows ahead of its pass 1
+// (two small launches, ~13 us), and runs eagerly.  Only that one: measured over the first 32 iterations the band's ratio
+// did worse than the recurrences once the step lengths alternate (the shape of the prefix sums alternates with them),
+// and a few iterations around the 20th, where that pattern sets in, miss either way.
+constexpr int kBandIters = 1;
+
 // Rows at each end of a rank's block that the lean schedule's second pass computes in launches of their own,
 // ahead of the rest, so that the new gradient's boundary rows can travel while the other rows are computed.
 constexpr long kEdgeRows = 8;
@@ -712,7 +724,18 @@ int enqueue_lean_iteration(cg_ctx *c)
     const bool spec = strict && strict_speculative(c, t);
     a.sub = sub;
     a.rec = c->xs.rec;
+    if (!spec) c->band_left = 0;
     if (spec) {
+        if (c->band_left > 0) {
+            // the first iterations behind a leading one: the growth of d.q from a band of rows, evaluated ahead of the pass
+            --c->band_left;
+            StencilArgs ab = a;
+            ab.sub = nullptr; ab.partials = c->partials + 2 * c->npart;
+            const long nb = launch_stencil<3, false>(tq, ab, s, c->band_lo, c->band_hi, 0);
+            hipLaunchKernelGGL(cg::exact::k_band_rho, dim3(1), dim3(64), 0, s, (const double *)ab.partials, nb,
+                               c->strict_slot + 4, c->sc, c->xs.skip);
+            HIPCHK(hipGetLastError());
+        }
         a.hyp = c->xs.hyp[0]; a.hyp_which = 0;
         a.partials2 = c->partials + 2 * c->npart;
         launch_stencil<3, false, 2>(tq, a, s);
@@ -959,7 +982,15 @@ int enqueue_iteration(cg_ctx *c, bool first)
     // this one hands them its approximate prefix sums (without them the first of them would summarise every chunk twice).
     const bool seed = lean && sub != nullptr && strict_speculative(c, t) && c->strict_blocks <= 1 &&
                       use_parallel_strict(c->strict_impl, c->count);
-    if (seed) { cg::exact::spec_seed(s, c->xs, c->G, c->rows, 0); HIPCHK(hipGetLastError()); }
+    if (seed) {
+        cg::exact::spec_seed(s, c->xs, c->G, c->rows, 0);
+        c->band_lo = c->rows > 64 ? c->rows / 2 - 32 : 0;
+        c->band_hi = c->rows > 64 ? c->band_lo + 64 : c->rows;
+        hipLaunchKernelGGL(cg::exact::k_band_sum, dim3(1), dim3(256), 0, s, (const double *)sub, c->G, c->rows, c->band_lo, c->band_hi,
+                           c->strict_slot + 4, c->xs.skip);
+        HIPCHK(hipGetLastError());
+        c->band_left = c->live ? 0 : kBandIters;      // a solve that continues another has its scalars' history to predict from
+    }
 
     // ---- u += tau d ; g += tau q (+ g.g)
     double *gg_sub = nullptr;
@@ -2041,11 +2072,12 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
     };
     long launched = 0;
     bool stopped = false;
+    if (sched != CG_SCHED_LEAN || c->reduce != CG_REDUCE_STRICT) c->band_left = 0;
     if (lead) { CGCHK(enqueue_iteration(c, true)); launched = 1; }
     for (;;) {
         while (launched < max_iters && !stopped) {
             if (glen > 0 && max_iters - launched >= glen && graph->dcur == c->dcur && graph->gcur == c->gcur &&
-                graph->pend == c->lean_pending) {
+                graph->pend == c->lean_pending && c->band_left == 0) {     // (the first iterations behind a leading one have a step of their own: eager)
                 HIPCHK(hipGraphLaunch(graph->exec, s));
                 launched += glen;                           // an even number of iterations: the roles are as before
             } else {

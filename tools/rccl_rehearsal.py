@@ -48,6 +48,8 @@ for label, red, reh, chain, graph in (("fast order, no traffic", cg.REDUCE_FAST,
                                       ("strict, published briefs, hipGraph", cg.REDUCE_STRICT, P, 1, 10),
                                       ("strict, published briefs, eager", cg.REDUCE_STRICT, P, 1, 0),
                                       ("strict, ranks in turn, hipGraph", cg.REDUCE_STRICT, P, 0, 10)):
+    if reh and graph and red == cg.REDUCE_STRICT and os.environ.get("CG_REHEARSAL_EAGER"):
+        continue                                           # (rocprofv3's kernel trace crashes on these captured graphs; the eager flavour is traced instead)
     t = cg.CGSolver(n2)
     if reh:
         t.comm_init(cg.CGSolver.comm_unique_id())
@@ -61,5 +63,5 @@ for label, red, reh, chain, graph in (("fast order, no traffic", cg.REDUCE_FAST,
     calls = 0 if not reh else (3 if red == cg.REDUCE_FAST else 1 + 2 * (2 if chain else P + 1))
     print(f"{n2 + 1}^2 {label:36s}: {per:8.1f} us per iteration, RCCL calls per iteration: {calls}, q1={float(r.q1).hex()}", flush=True)
     t.close()
-print(f"strict (published briefs) / fast order, both with the traffic of {P} ranks: "
-      f"{rate['strict, published briefs, hipGraph'] / rate['fast order, rehearsed']:.2f}", flush=True)
+pub = rate.get("strict, published briefs, hipGraph", rate["strict, published briefs, eager"])
+print(f"strict (published briefs) / fast order, both with the traffic of {P} ranks: {pub / rate['fast order, rehearsed']:.2f}", flush=True)
