@@ -279,6 +279,7 @@ struct SrcStencil {
     Coef9 coef;
     long G, rows, row0, count;                          // G a multiple of kChunk: a chunk lies inside one row
     double beta;
+    int plain;                                          // d holds d' itself (the iteration that starts a solve): beta and g stay out of it
     // d' of one row segment with its two outer columns.  Every lane reads 16 consecutive columns, so column x sits
     // at x + 2 + floor(x / 16): the lanes' blocks start 17 doubles apart and fall on different LDS banks (a stride
     // of 16 doubles would put 32 lanes on the same bank).
@@ -286,7 +287,7 @@ struct SrcStencil {
     static constexpr int kLds = 3 * kRow;
     static __device__ __forceinline__ int at(int x) { return x + 2 + (x >> 4); }      // x = -1 .. kChunk
     __device__ __forceinline__ void prepare() { beta = sc->beta; }
-    __device__ __forceinline__ double dp(long k) const { return beta * d[k] - g[k]; }
+    __device__ __forceinline__ double dp(long k) const { return plain ? d[k] : beta * d[k] - g[k]; }
     __device__ __forceinline__ double product(long k) const
     {
         const long m = k / G, j = k - m * G, gi = row0 + m;
@@ -327,8 +328,8 @@ struct SrcStencil {
 #pragma unroll
             for (int k = 0; k < kChunk / 128; ++k) {
                 double *dst = T + rr * kRow + at(k * 128 + 2 * lane);        // an even column and its neighbour: one block of 16
-                dst[0] = beta * dv[rr][k].x - gv[rr][k].x;
-                dst[1] = beta * dv[rr][k].y - gv[rr][k].y;
+                dst[0] = plain ? dv[rr][k].x : beta * dv[rr][k].x - gv[rr][k].x;
+                dst[1] = plain ? dv[rr][k].y : beta * dv[rr][k].y - gv[rr][k].y;
             }
         if (lane < 6) T[(lane % 3) * kRow + ((lane < 3) ? at(-1) : at(kChunk))] = edge;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

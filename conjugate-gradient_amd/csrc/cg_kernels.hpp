@@ -178,6 +178,7 @@ struct StencilArgs {
     long ntiles_launch;               // tiles this launch covers (>= its workgroup count)
     Coef9 coef;                       // stencil coefficients
     int store_products;               // WRITE_Q kernels: store d*q (rounded) where q would go
+    int plain_d;                      // MODE 3: d_in holds the direction itself (the iteration that starts a solve): beta and g stay out of it
     // Strict order, speculative summaries (kernels instantiated with NH = 2 only).  The unit is one workgroup's part
     // of a row, kUnit = 512 consecutive products; unit (strip, row r) has index strip * rows + r.  hyp[unit] is last
     // iteration's prefix sum at the unit; scaled by the predicted growth sc->rho[hyp_which] it gives the LOWER of two
@@ -563,7 +564,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     const double rho = (NH > 0) ? a.sc->rho[a.hyp_which] : 1.0;
 
     double beta = 0.0, tau = 0.0;
-    if (FUSE_D) beta = a.sc->beta;
+    // plain_d: d' = 1*d - 0 = d, bit for bit (g is read through a descriptor of no bytes: zeros, no memory traffic)
+    const bool plain_d = FUSE_D && a.plain_d != 0;
+    if (FUSE_D) beta = plain_d ? 1.0 : a.sc->beta;
     double tau_prev = 0.0;
     if (MODE == 2 || MODE == 4 || MODE == 5) tau = a.sc->tau;
     if (MODE == 5) tau_prev = a.sc->tau_ring[(a.sc->iter - 1) & 7];   // iteration i-1's tau; this pass belongs to iteration i
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
     // row and operand.
     const unsigned in_bytes = (unsigned)(r1 - r0 + 2) * (unsigned)rowbytes, own_bytes = (unsigned)(r1 - r0) * (unsigned)rowbytes;
     const __amdgpu_buffer_rsrc_t td = row_rsrc_nn(a.d_in + (long)(r0 - 1) * G, CONTIG ? (int)in_bytes : 0);
-    const __amdgpu_buffer_rsrc_t tg = row_rsrc_nn((FUSE_D ? a.g : a.d_in) + (long)(r0 - 1) * G, (CONTIG && FUSE_D) ? (int)in_bytes : 0);
+    const __amdgpu_buffer_rsrc_t tg = row_rsrc_nn((FUSE_D ? a.g : a.d_in) + (long)(r0 - 1) * G, (CONTIG && FUSE_D && !plain_d) ? (int)in_bytes : 0);
     // MODE 2 without u (a.u == nullptr: the update is left to the next iteration's paired one): descriptors of no
     // bytes, so the loads deliver zeros and the stores are dropped without touching memory
     const bool has_u = (MODE == 5) || (MODE == 2 && a.u != nullptr);
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
             raw.ed = buf_load1(rd, off_edge);
             if (FUSE_D) {
                 const double *pg = row_ptr(a.g, a.g_top, a.g_bot, r);
-                const __amdgpu_buffer_rsrc_t rg = row_rsrc(pg, live ? rowbytes : 0);
+                const __amdgpu_buffer_rsrc_t rg = row_rsrc(pg, (live && !plain_d) ? rowbytes : 0);
                 BufIO<VEC>::load(rg, off_main, raw.g);
                 raw.eg = buf_load1(rg, off_edge);
             } else {
@@ -727,10 +730,19 @@ __global__ __launch_bounds__(kBlock, (MODE == 3) ? ((NH > 0 && PF <= 2) ? 3 : 2)
                 BufIO<VEC>::store(row_rsrc_nn(a.u +(long)m * G, (row_own && has_u) ? rowbytes : 0), off_main, pu);
                 BufIO<VEC>::store(row_rsrc_nn(a.gw +(long)m * G, row_own ? rowbytes : 0), off_main, pg);
                 if (VEC == 2 && a.sub != nullptr) {                                // wave-uniform
-                    double span = pg[0] * pg[0];
-                    span += pg[VEC - 1] * pg[VEC - 1];
-                    span = wave_sum_unordered(span);
-                    if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
+                    double prod[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) prod[v] = pg[v] * pg[v];
+                    double span = prod[0];
+                    span += prod[VEC - 1];
+                    if (NH == 0) {
+                        span = wave_sum_unordered(span);
+                        if ((tid & 63) == 63 && row_own && j < G) a.sub[(j >> 7) * a.rows + m] = span;
+                    } else {
+                        bool t0, t1;
+                        const SpanEntry e = span_entry<VEC, true>(prod, hyp_exponent(mid_hyp, rho), t0, t1);
+                        span4_push_lds<true>(span_R, span_X, p, e, t0, t1);
+                    }
                 }
             } else if (MODE == 4 || MODE == 5) {
                 double pg[VEC];

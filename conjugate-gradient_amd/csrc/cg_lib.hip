@@ -278,6 +278,7 @@ struct cg_ctx {
     int band_left = 0;                    // strict order, lean schedule: so many of the next iterations predict the growth of d.q from a band
                                           // of rows (the band's last sum is in strict_slot[4]; cg_exact.hpp, k_band_sum)
     long band_lo = 0, band_hi = 0;
+    bool hyp_valid = false;               // strict order: the hypotheses in the workspace stem from an iteration of the present problem
     bool lead_defers_u = false;           // lean schedule: the leading iteration of the present solve leaves its u update to the first pair
     bool strict_safe = false;             // the iteration being enqueued completes a faulted dot product: ranks walk in turn
     long fault_every = 0;                 // test hook: the published walk declares every n-th dot product failed
@@ -692,11 +693,15 @@ constexpr long kEdgeRows = 8;
 // launch for the rows in between on the main stream (the reference's post - interior - wait - edges of
 // utils.c:45-104, with the edges first because it is their OUTPUT that travels here); the streams join
 // before the dot product is completed, so every iteration is self-contained (capturable as it stands).
-int enqueue_lean_iteration(cg_ctx *c)
+// lead: the iteration that starts a solve, in this form (single rank, strict order with hypotheses at hand): d[dcur] holds
+// the direction itself, so pass 1 reads it alone (plain_d), and pass 2 is the in-place update of the schedule without q
+// (MODE 2: recompute q, g += tau*q, u += tau*d unless cg_solve defers that) with the span sums formed inside; nothing
+// changes roles.
+int enqueue_lean_iteration(cg_ctx *c, bool lead = false)
 {
     hipStream_t s = c->stream;
     const TileGeom t = ctx_geom(c), tq = dq_geom(c, t);
-    const bool overlap = c->multi() && c->overlap && c->rows >= 4 * kEdgeRows;
+    const bool overlap = !lead && c->multi() && c->overlap && c->rows >= 4 * kEdgeRows;
     TileGeom ti = t;                                       // pass 2, rows between the edge strips
     long n_gg = t.ntiles;
     if (overlap) {
@@ -709,10 +714,11 @@ int enqueue_lean_iteration(cg_ctx *c)
     double *p_dq, *p_gg;
     CGCHK(rank_partials(c, c->partials, tq.ntiles, &p_dq));
     CGCHK(rank_partials(c, c->partials + c->npart, n_gg, &p_gg));
-    const int in = c->dcur, out = c->dcur ^ 1;
+    const int in = c->dcur, out = lead ? c->dcur : c->dcur ^ 1;
     StencilArgs a = base_args(c, tq);
     a.partials = p_dq;
     a.d_in = c->d[in]; a.g = c->g;
+    a.plain_d = lead ? 1 : 0;
     a.d_top = c->has_top() ? c->halo_d[in][0] : nullptr;
     a.d_bot = c->has_bot() ? c->halo_d[in][1] : nullptr;
     a.g_top = c->has_top() ? c->halo_g[0] : nullptr;
@@ -743,6 +749,7 @@ int enqueue_lean_iteration(cg_ctx *c)
         cg::exact::SrcStencil src;
         src.d = c->d[in]; src.g = c->g; src.sc = c->sc; src.coef = c->coef;
         src.G = c->G; src.rows = c->rows; src.row0 = c->row0; src.count = c->count; src.beta = 0.0;
+        src.plain = lead ? 1 : 0;
         const double *at = nullptr;
         auto f_approx = [&](double *total) { cg::exact::spec_approx(s, c->xs, c->G, c->rows, total); };
         auto f_summ = [&](const double *seed, int nseed) {
@@ -784,11 +791,14 @@ int enqueue_lean_iteration(cg_ctx *c)
     b.d_out = c->d[out];
     b.d_top_out = c->has_top() ? c->halo_d[out][0] : nullptr;
     b.d_bot_out = c->has_bot() ? c->halo_d[out][1] : nullptr;
-    b.g_out = c->g_buf[c->gcur ^ 1];
+    b.g_out = lead ? c->g : c->g_buf[c->gcur ^ 1];
     b.u = c->u;
-    const bool with_u = c->lean_pending == 1;             // the previous iteration's u update is outstanding: do both
+    // the previous iteration's u update is outstanding: do both (a leading iteration: its own, unless it is deferred)
+    const bool with_u = lead ? !c->lead_defers_u : c->lean_pending == 1;
     if (spec) { b.hyp = c->xs.hyp[1]; b.hyp_which = 1; }
+    if (lead) { b.plain_d = 0; b.gw = c->g; b.d_out = nullptr; if (!with_u) b.u = nullptr; }
     auto pass2 = [&](hipStream_t on, const TileGeom &tg, long lo, long hi, long base) -> long {
+        if (lead) return launch_stencil<2, false, 2>(tg, b, on, lo, hi, base);
         if (spec) return with_u ? launch_stencil<5, false, 2>(tg, b, on, lo, hi, base) : launch_stencil<4, false, 2>(tg, b, on, lo, hi, base);
         return with_u ? launch_stencil<5, false>(tg, b, on, lo, hi, base) : launch_stencil<4, false>(tg, b, on, lo, hi, base);
     };
@@ -837,6 +847,11 @@ int enqueue_lean_iteration(cg_ctx *c)
                                c->hist, c->hist_cap);
     } else {
         CGCHK(enqueue_dot_finish(c, b.g_out, b.g_out, p_gg, n_gg, with_u ? 1 : 4, 0.0, sub ? 2 : 0));
+    }
+    if (spec) c->hyp_valid = true;
+    if (lead) {
+        c->lean_pending = with_u ? 0 : 1;
+        return CG_OK;
     }
     c->dcur = out;
     c->set_gcur(c->gcur ^ 1);
@@ -889,7 +904,12 @@ int enqueue_iteration(cg_ctx *c, bool first)
     const bool lean = sched == CG_SCHED_LEAN;
     if (lean) {
         if (!first) return enqueue_lean_iteration(c);
-        sched = CG_SCHED_FUSED_NOQ;       // d is materialised: stencil pass + in-place update pass, as there
+        // d is materialised.  With hypotheses of this problem at hand (a solve that continues another one) the iteration
+        // runs in the lean form all the same; else as stencil pass + in-place update pass with stored products.
+        if (c->hyp_valid && !c->multi() && c->reduce == CG_REDUCE_STRICT && c->strict_blocks <= 1 &&
+            strict_speculative(c, ctx_geom(c)))
+            return enqueue_lean_iteration(c, true);
+        sched = CG_SCHED_FUSED_NOQ;
     }
     // The lean schedule applies u's updates in pairs; cg_solve may ask the leading iteration to leave its own to the
     // first pair (then a solve of an even number of iterations ends with none left over).
@@ -1115,6 +1135,7 @@ int build_graph(cg_ctx *c, long len, GraphSlot **out)
     *slot = GraphSlot();
     hipGraph_t graph = nullptr;
     const int dcur0 = c->dcur, gcur0 = c->gcur, pend0 = c->lean_pending;
+    const bool hyp0 = c->hyp_valid;
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = CG_OK;
     for (long i = 0; i < len && rc == CG_OK; ++i) rc = enqueue_iteration(c, false);
@@ -1122,6 +1143,7 @@ int build_graph(cg_ctx *c, long len, GraphSlot **out)
     c->dcur = dcur0;                       // capture executed nothing
     c->set_gcur(gcur0);
     c->lean_pending = pend0;
+    c->hyp_valid = hyp0;
     if (rc != CG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(CG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
     e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
@@ -1894,6 +1916,7 @@ int cg_init_problem(cg_ctx *c)
     c->d_halo_stale = false;
     c->q_valid = true;
     c->xs.forget_hypotheses();
+    c->hyp_valid = false;
     HIPCHK(hipMemsetAsync(c->u, 0, bytes, s));           // calloc, cg.c:44
     HIPCHK(hipMemsetAsync(c->q, 0, bytes, s));           // calloc, cg.c:45
     const int fb = flat_blocks(c->count, 0);
@@ -2178,7 +2201,7 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
                     t.ntiles > tq.ntiles ? t.ntiles : tq.ntiles, c->npart);
     // From here on the vectors and the device scalars are scratch: nothing owed, nothing to continue, and
     // no solve or read-back until cg_init_problem has set the problem up again.
-    c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->needs_init = true;
+    c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->needs_init = true; c->hyp_valid = false;
     bool spec = false;
     if (sched == CG_SCHED_LEAN && c->reduce == CG_REDUCE_STRICT && c->strict_spec &&
         c->G % cg::exact::kChunk == 0 && use_parallel_strict(c->strict_impl, c->count)) {

@@ -286,6 +286,27 @@ def test_leading_iteration_hands_its_prefix_sums_to_the_first_speculating_iterat
         s.close(); b.close()
 
 
+def test_solves_that_restart_from_materialised_vectors_keep_the_bits(cg, oracle):
+    # Reading a vector between two solves has the owed d and u updates applied, so the next solve starts from a
+    # materialised direction: with the last solve's hypotheses at hand its leading iteration runs in the lean form
+    # (pass 1 on d alone, the in-place update pass with the span sums inside), with its u update applied at once or
+    # left to the first pair, whichever the count of iterations behind it asks for.
+    n = 1023
+    counts = (3, 1, 4, 2, 7, 6, 9)
+    ref = oracle.cg(n, sum(counts))
+    s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, graph_iters=4).init_problem()
+    hist, done = [], 0
+    for k in counts:
+        s.solve(k)
+        hist.append(s.history(k))
+        done += k
+        mid = oracle.cg(n, done)
+        for key, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):     # (materialises)
+            assert np.array_equal(bits(s.vector(which)), bits(mid[key])), (key, done)
+    assert np.array_equal(bits(np.concatenate(hist)), bits(ref["hist"]))
+    s.close()
+
+
 def test_speculative_summaries_continue_across_solves_and_stop_rule(cg, oracle):
     n = 1023
     ref = oracle.cg(n, 120)
