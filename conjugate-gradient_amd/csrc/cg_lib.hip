@@ -1587,29 +1587,35 @@ static int choose_placement(cg_ctx *c)
     // pair 1, and the other way round: the same kernel can differ by 10 % between them), the six-stream pass with one
     // and with two rows in flight (which is better depends on the set).  A solve runs the four-stream pass in one
     // direction and the six-stream pass in the other throughout, and cg_solve picks the cheaper assignment.
+    // Where the grid allows it the passes are timed in the form the reference's summation order gives them (span sums
+    // formed inside: more instructions, two small extra streams), the form the bit-exact solves run; the six-stream pass
+    // of the plain form is timed as well, both directions in turn, to settle its rows in flight.
     struct Cost { double ms; int pf; double pass[3][2]; };
+    const int reduce0 = c->reduce;
     auto cost = [&](Cost *out) -> int {
-        double t[4][2];
+        double t[3][2], six[2] = {0.0, 0.0};
         c->time_warm = 1;
+        c->reduce = CG_REDUCE_STRICT;                   // (cg_time_kernel falls back on the plain form by itself where the grid asks for it)
         int rc = CG_OK;
-        for (int which = 0; which < 4 && rc == CG_OK; ++which)
+        for (int which = 0; which < 3 && rc == CG_OK; ++which)
             for (int dir = 0; dir < 2 && rc == CG_OK; ++dir) {
-                c->pf_update_u = (which == 3) ? 1 : 2;
+                c->pf_update_u = 2;
                 c->time_dir = dir;
-                rc = cg_time_kernel(c, which < 3 ? which : 2, 2, &t[which][dir], nullptr);
+                rc = cg_time_kernel(c, which, 2, &t[which][dir], nullptr);
             }
-        c->time_dir = -1; c->time_warm = 2;
-        if (rc != CG_OK) return rc;
-        out->ms = 1e30;
-        for (int pf = 1; pf <= 2; ++pf) {
-            const double *six = t[pf == 1 ? 3 : 2];
-            const double best6 = (t[1][0] + six[1] < t[1][1] + six[0]) ? t[1][0] + six[1] : t[1][1] + six[0];
-            const double ms = t[0][0] + t[0][1] + best6;
-            if (ms < out->ms) {
-                out->ms = ms; out->pf = pf;
-                for (int dir = 0; dir < 2; ++dir) { out->pass[0][dir] = t[0][dir]; out->pass[1][dir] = t[1][dir]; out->pass[2][dir] = six[dir]; }
-            }
+        c->reduce = CG_REDUCE_FAST;
+        c->time_dir = -1;
+        for (int pf = 1; pf <= 2 && rc == CG_OK; ++pf) {
+            c->pf_update_u = pf;
+            rc = cg_time_kernel(c, 2, 2, &six[pf - 1], nullptr);
         }
+        c->reduce = reduce0;
+        c->time_warm = 2;
+        if (rc != CG_OK) return rc;
+        const double best6 = (t[1][0] + t[2][1] < t[1][1] + t[2][0]) ? t[1][0] + t[2][1] : t[1][1] + t[2][0];
+        out->ms = t[0][0] + t[0][1] + best6;
+        out->pf = six[0] < six[1] ? 1 : 2;
+        memcpy(out->pass, t, sizeof t);
         return CG_OK;
     };
     // diagnostic: CG_PLACEMENT_KEEP=worst keeps the slowest set instead (to put a slow placement under the profiler)
