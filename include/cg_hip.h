@@ -216,8 +216,10 @@ typedef struct cg_ctx cg_ctx;
 /* A context owns the row block [row0, row0+rows) x (n+1) of u, g, d, q on
  * `device`.  Single GPU: row0 = 0, rows = n+1, rank 0 of 1.
  * Blocks of 2^27 points or more: the vectors are allocated up to eight times over, the passes of the default schedule
- * timed on each set, the fastest placement kept and the rest released (about 0.35 s, once; where the driver puts a
- * vector in HBM changes the passes' speed by 5 % and more).  CG_PLACEMENT_DRAWS=1 in the environment turns that off. */
+ * timed on each set (in both directions of the buffer pairs), the fastest placement kept, single vectors of it traded
+ * against those of the other sets where that makes the passes faster, and the rest released (1.5-2 s, once; where the
+ * driver puts a vector in HBM changes the passes' speed by 5 % and more: which L2 sets the streams of a pass compete
+ * for).  In the environment, CG_PLACEMENT_REFINE=0 skips the trades (0.35 s) and CG_PLACEMENT_DRAWS=1 the whole search. */
 int cg_create(cg_ctx **out, int device, long n, long row0, long rows, int rank, int nranks);
 int cg_destroy(cg_ctx *ctx);
 int cg_set_option(cg_ctx *ctx, int key, long value);
