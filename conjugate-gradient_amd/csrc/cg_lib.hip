@@ -1136,6 +1136,8 @@ int build_graph(cg_ctx *c, long len, GraphSlot **out)
     hipGraph_t graph = nullptr;
     const int dcur0 = c->dcur, gcur0 = c->gcur, pend0 = c->lean_pending;
     const bool hyp0 = c->hyp_valid;
+    const int band0 = c->band_left;
+    c->band_left = 0;                      // (the step of an iteration behind a leading one is never part of a graph)
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = CG_OK;
     for (long i = 0; i < len && rc == CG_OK; ++i) rc = enqueue_iteration(c, false);
@@ -1144,6 +1146,7 @@ int build_graph(cg_ctx *c, long len, GraphSlot **out)
     c->set_gcur(gcur0);
     c->lean_pending = pend0;
     c->hyp_valid = hyp0;
+    c->band_left = band0;
     if (rc != CG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(CG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
     e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
