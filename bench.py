@@ -244,7 +244,10 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         s.set_option(cg.lib.OPT_RESUM_Q0, 0)
-        s.solve(2)                               # leaves the state a steady-state iteration starts from
+        # A solve long enough for the library to settle which pass keeps which direction of the buffer pairs for good
+        # (cg_solve decides that at its leading iteration from the count of iterations behind it); the K iterations that
+        # continue it are the steady state.
+        s.solve(args.steps + 2)
         st = s.solve(args.steps)
         steady = st.seconds / max(st.iters, 1)
         if world > 1:

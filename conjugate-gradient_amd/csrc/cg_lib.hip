@@ -2022,6 +2022,10 @@ int cg_solve(cg_ctx *c, long max_iters, double rtol, cg_result *out)
         const double deferred = (double)((n + 1) / 2) * m5[0] + (double)(n / 2) * m4[1] + ((n > 0 && !(n & 1)) ? flush : 0.0) - lead_u;
         const double at_once = (double)((n + 1) / 2) * m4[0] + (double)(n / 2) * m5[1] + ((n & 1) ? flush : 0.0);
         c->lead_defers_u = n > 0 && deferred < at_once;
+        if (const char *e = getenv("CG_LEAD_DEFER_U")) c->lead_defers_u = n > 0 && atoi(e) != 0;      // diagnostic override
+        if (getenv("CG_DEBUG_PLACEMENT"))
+            fprintf(stderr, "pairing: %ld iterations behind the leading one from direction %d: deferred %.3f, at once %.3f -> %s\n", n, d0,
+                    deferred, at_once, c->lead_defers_u ? "deferred" : "at once");
     }
     struct PendGuard {                      // the graph is chosen for the state the leading iteration will leave
         cg_ctx *c; int saved;
