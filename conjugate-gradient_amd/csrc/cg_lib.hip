@@ -2212,6 +2212,14 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     if (t.ntiles > c->npart || tq.ntiles > c->npart)
         return fail(CG_ERR_ARG, "%ld tiles exceed the %ld partial sums the context holds: use a larger CG_OPT_TILE_H",
                     t.ntiles > tq.ntiles ? t.ntiles : tq.ntiles, c->npart);
+    // Lean schedule: the four- and the six-stream pass alternate, so each reads the same buffer pair in every one of its
+    // launches of a solve; the timing keeps the pair the solve that ran last would have given the pass next (the read-only
+    // pass runs in both directions in turn, as it does in a solve).
+    int own_dir = -1;
+    if (sched == CG_SCHED_LEAN && c->time_dir < 0 && c->live && (which == 1 || which == 2)) {
+        const int next_u = (c->lean_pending == 1) ? c->dcur : c->dcur ^ 1;     // the pair the next pass with the u update reads
+        own_dir = (which == 2) ? next_u : next_u ^ 1;
+    }
     // From here on the vectors and the device scalars are scratch: nothing owed, nothing to continue, and
     // no solve or read-back until cg_init_problem has set the problem up again.
     c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->needs_init = true; c->hyp_valid = false;
@@ -2231,7 +2239,8 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     double per_point = 0.0;
     auto launch = [&]() {
         if (sched == CG_SCHED_LEAN) {
-            if (c->time_dir >= 0) { c->dcur = c->time_dir; c->set_gcur(c->time_dir); }
+            const int fixed_dir = c->time_dir >= 0 ? c->time_dir : own_dir;
+            if (fixed_dir >= 0) { c->dcur = fixed_dir; c->set_gcur(fixed_dir); }
             StencilArgs a = base_args(c, which == 0 ? tq : t);
             const int out = c->dcur ^ 1;
             a.partials = c->partials; a.d_in = c->d[c->dcur]; a.g = c->g;

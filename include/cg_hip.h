@@ -281,7 +281,10 @@ int cg_get_history(cg_ctx *ctx, double *host_dst, long count, long *written);
  * which, for the default LEAN schedule (with CG_REDUCE_STRICT the passes also form their span sums):
  *        0 = pass 1 (reads d, g; d.q),            16 B/point
  *        1 = pass 2 (reads d, g; writes d', g'),  32 B/point
- *        2 = pass 2 with the paired u update,     48 B/point;
+ *        2 = pass 2 with the paired u update,     48 B/point
+ *        (the two kinds of pass 2 alternate, so in a solve each of them always reads the same one of the two buffer pairs
+ *        and writes the other, and the two directions can differ by 10 %: called after a solve, 1 and 2 are timed in the
+ *        direction that solve's next such pass would have run in; on a fresh context the launches alternate);
  * for CLASSIC / FUSED / FUSED_NOQ:
  *        0 = stencil kernel (as scheduled: with the fused d-update if any),
  *        1 = update kernel, 2 = d-update kernel (CLASSIC only).
