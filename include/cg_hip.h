@@ -256,7 +256,12 @@ typedef struct cg_result {
  * applied by the next cg_solve (as part of its first iteration) or by whatever
  * looks at the vectors first: cg_copy_out, cg_device_ptr, cg_sync_vectors,
  * cg_set_option, cg_set_stencil.  With several ranks that step exchanges halo
- * rows, so those calls are collective there: make them on every rank.        */
+ * rows, so those calls are collective there: make them on every rank.
+ * Lean schedule: the two kinds of second pass alternate, so each of them always reads the same one of the two
+ * buffer pairs, and the pairs can differ in speed (cg_create).  Which pass gets which is settled by the first
+ * iteration of a solve that starts from applied updates, from the count of iterations behind it; a solve that
+ * merely continues another one inherits it, and, on one rank, where cg_create measured the passes, applies the owed
+ * updates and starts over when the other assignment would pay within max_iters.  `seconds` does not count that step. */
 int cg_solve(cg_ctx *ctx, long max_iters, double rtol, cg_result *out);
 /* Apply the updates the last solve left owed (see cg_solve): afterwards u, g and d hold
  * what the reference's loop holds after the same iterations.                 */

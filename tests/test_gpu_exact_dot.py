@@ -307,6 +307,32 @@ def test_solves_that_restart_from_materialised_vectors_keep_the_bits(cg, oracle)
     s.close()
 
 
+def test_placement_search_and_pairing_choices_do_not_touch_the_bits(cg, oracle, monkeypatch):
+    # A context for a large grid draws sets of vectors, trades single vectors between them, times the lean passes per
+    # direction, and cg_solve uses those times to decide which of the two kinds of pass 2 reads which buffer pair (also:
+    # whether a continuing solve should start over for the other assignment).  Here the search runs on a small grid, and
+    # both pairings are forced in turn: every bit must be what the restatement gives.
+    n = 1023
+    monkeypatch.setenv("CG_PLACEMENT_MIN_POINTS", "1")
+    monkeypatch.setenv("CG_PLACEMENT_DRAWS", "3")
+    ref = oracle.cg(n, 3 + 40 + 41)
+    for forced in ("0", "1", None):
+        s = cg.CGSolver(n).configure(reduce=cg.REDUCE_STRICT, graph_iters=4).init_problem()
+        if forced is None:
+            monkeypatch.delenv("CG_LEAD_DEFER_U", raising=False)
+        else:
+            monkeypatch.setenv("CG_LEAD_DEFER_U", forced)
+        hist = []
+        s.solve(3); hist.append(s.history(3))
+        monkeypatch.delenv("CG_LEAD_DEFER_U", raising=False)
+        s.solve(40); hist.append(s.history(40))           # a pure continuation: may start over for the other assignment
+        s.solve(41); hist.append(s.history(41))
+        assert np.array_equal(bits(np.concatenate(hist)), bits(ref["hist"])), forced
+        for key, which in (("u", cg.VEC_U), ("g", cg.VEC_G), ("d", cg.VEC_D)):
+            assert np.array_equal(bits(s.vector(which)), bits(ref[key])), (forced, key)
+        s.close()
+
+
 def test_speculative_summaries_continue_across_solves_and_stop_rule(cg, oracle):
     n = 1023
     ref = oracle.cg(n, 120)
