@@ -278,6 +278,8 @@ struct cg_ctx {
     int band_left = 0;                    // strict order, lean schedule: so many of the next iterations predict the growth of d.q from a band
                                           // of rows (the band's last sum is in strict_slot[4]; cg_exact.hpp, k_band_sum)
     long band_lo = 0, band_hi = 0;
+    int u_dir = -1;                       // lean schedule: the buffer pair the pass with the u update read in the last solve (-1: no solve yet);
+                                          // cg_time_kernel times the two kinds of pass 2 accordingly
     bool hyp_valid = false;               // strict order: the hypotheses in the workspace stem from an iteration of the present problem
     bool lead_defers_u = false;           // lean schedule: the leading iteration of the present solve leaves its u update to the first pair
     bool strict_safe = false;             // the iteration being enqueued completes a faulted dot product: ranks walk in turn
@@ -1928,6 +1930,7 @@ int cg_init_problem(cg_ctx *c)
     c->q_valid = true;
     c->xs.forget_hypotheses();
     c->hyp_valid = false;
+    c->u_dir = -1;
     HIPCHK(hipMemsetAsync(c->u, 0, bytes, s));           // calloc, cg.c:44
     HIPCHK(hipMemsetAsync(c->q, 0, bytes, s));           // calloc, cg.c:45
     const int fb = flat_blocks(c->count, 0);
@@ -2234,10 +2237,9 @@ int cg_time_kernel(cg_ctx *c, int which, int reps, double *ms_per_launch, double
     // launches of a solve; the timing keeps the pair the solve that ran last would have given the pass next (the read-only
     // pass runs in both directions in turn, as it does in a solve).
     int own_dir = -1;
-    if (sched == CG_SCHED_LEAN && c->time_dir < 0 && c->live && (which == 1 || which == 2)) {
-        const int next_u = (c->lean_pending == 1) ? c->dcur : c->dcur ^ 1;     // the pair the next pass with the u update reads
-        own_dir = (which == 2) ? next_u : next_u ^ 1;
-    }
+    if (sched == CG_SCHED_LEAN && c->live) c->u_dir = (c->lean_pending == 1) ? c->dcur : c->dcur ^ 1;   // the pair the next pass with the u update reads
+    if (sched == CG_SCHED_LEAN && c->time_dir < 0 && c->u_dir >= 0 && (which == 1 || which == 2))
+        own_dir = (which == 2) ? c->u_dir : c->u_dir ^ 1;
     // From here on the vectors and the device scalars are scratch: nothing owed, nothing to continue, and
     // no solve or read-back until cg_init_problem has set the problem up again.
     c->pending_dupdate = false; c->lean_pending = 0; c->live = false; c->needs_init = true; c->hyp_valid = false;
